@@ -1,0 +1,257 @@
+"""ORACLE / TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz|json.
+
+Runs in the AUTHORING container only (needs /root/reference; the GPU box has no
+reference tree and only consumes the committed fixtures).
+
+What is executed for real from the reference (read-only, never copied):
+    graph_recsys_benchmark/models/base.py      GraphRecsysModel.loss / .eval,
+                                               PEABaseChannel.forward, PEABaseRecsysModel.*
+    graph_recsys_benchmark/models/pea{gat,gcn,sage}.py   channel construction
+    graph_recsys_benchmark/utils/rec_utils.py  hit / ndcg / auc
+They are loaded file-by-file through importlib under hand-made *package shells*
+(so the reference's package __init__ chain, which needs torch_geometric datasets,
+pandas pickles etc., never runs).  The only third-party names those files touch
+are torch_geometric.nn.inits.{glorot,zeros} and torch_geometric.nn.{GATConv,
+GCNConv,SAGEConv}; torch-geometric is not installed here, so those names are
+bound to oracle/pyg_restatement.py (spec restatement, parity of the conv
+arithmetic unpinned -- see its header).  Everything downstream of the convs in
+the fixtures (relu chain, channel stack, ablation mask, att/mean fusion,
+predict MLP, BPR loss, entity-aware term, eval() cache) is the reference's own
+code acting on those conv outputs.
+
+Fixtures are numbers only: inputs (x, parameters, edge lists, batches) and
+outputs (per-channel reps, fused cached_repr, predictions, losses).
+"""
+import importlib
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+import pyg_restatement as R  # noqa: E402
+
+
+def load_reference_models():
+    tg = types.ModuleType('torch_geometric')
+    tgnn = types.ModuleType('torch_geometric.nn')
+    inits = types.ModuleType('torch_geometric.nn.inits')
+    inits.glorot, inits.zeros = R.glorot, R.zeros
+    tgnn.inits = inits
+    tgnn.GATConv, tgnn.GCNConv, tgnn.SAGEConv = R.GATConv, R.GCNConv, R.SAGEConv
+    tg.nn = tgnn
+    sys.modules.update({'torch_geometric': tg, 'torch_geometric.nn': tgnn,
+                        'torch_geometric.nn.inits': inits})
+    pkg = types.ModuleType('graph_recsys_benchmark')
+    pkg.__path__ = [os.path.join(REF, 'graph_recsys_benchmark')]
+    mp = types.ModuleType('graph_recsys_benchmark.models')
+    mp.__path__ = [os.path.join(REF, 'graph_recsys_benchmark', 'models')]
+    up = types.ModuleType('graph_recsys_benchmark.utils')
+    up.__path__ = [os.path.join(REF, 'graph_recsys_benchmark', 'utils')]
+    sys.modules.update({'graph_recsys_benchmark': pkg, 'graph_recsys_benchmark.models': mp,
+                        'graph_recsys_benchmark.utils': up})
+    mods = {k: importlib.import_module('graph_recsys_benchmark.models.' + k)
+            for k in ('base', 'peagat', 'peagcn', 'peasage')}
+    if not hasattr(np, 'int'):
+        np.int = int      # utils/rec_utils.py:21 uses the alias removed in numpy 1.24
+    mods['rec_utils'] = importlib.import_module('graph_recsys_benchmark.utils.rec_utils')
+    return mods
+
+
+def tiny_hin(seed, n_user=60, n_item=90, n_attr=12, n_tag=14, e_u2i=900):
+    """A small HIN in the reference's id layout (contiguous per-type blocks) with the
+    features that matter for parity: multi-edges (tag relations), a hub item, isolated
+    nodes, and explicit self loops in one relation (dropped by GAT/GCN, kept by SAGE)."""
+    rng = np.random.default_rng(seed)
+    u0, i0, a0, t0 = 0, n_user, n_user + n_item, n_user + n_item + n_attr
+    n = t0 + n_tag + 5                     # 5 isolated trailing nodes
+    users = rng.integers(u0, i0, size=e_u2i)
+    pop = rng.zipf(1.3, size=e_u2i) % n_item
+    items = i0 + pop
+    hub = np.stack([np.arange(u0, i0), np.full(n_user, i0)])          # every user -> item 0
+    u2i = np.concatenate([np.stack([users, items]), hub], axis=1)
+    attr2item = np.stack([a0 + rng.integers(0, n_attr, size=150), i0 + rng.integers(0, n_item, size=150)])
+    tag2item = np.stack([t0 + rng.integers(0, n_tag, size=200), i0 + rng.integers(0, n_item, size=200)])
+    tag2item = np.concatenate([tag2item, tag2item[:, :40]], axis=1)    # repeated pairs
+    tag2user = np.stack([t0 + rng.integers(0, n_tag, size=120), u0 + rng.integers(0, n_user, size=120)])
+    loops = np.stack([np.arange(i0, i0 + 7), np.arange(i0, i0 + 7)])
+    tag2user = np.concatenate([tag2user, loops], axis=1)               # explicit self loops
+    rel = {'user2item': u2i, 'attr2item': attr2item, 'tag2item': tag2item, 'tag2user': tag2user}
+    rel = {k: torch.from_numpy(v.astype(np.float64)).long() for k, v in rel.items()}
+    return n, dict(u=(u0, i0), i=(i0, a0)), rel
+
+
+def metapaths(rel, which):
+    f = lambda t: torch.flip(t, dims=[0])       # utils/general_utils.py:300-308 idiom
+    u2i, a2i, t2i, t2u = rel['user2item'], rel['attr2item'], rel['tag2item'], rel['tag2user']
+    full = [[u2i, f(u2i)], [f(u2i), u2i], [a2i, f(u2i)], [t2i, f(u2i)], [t2u, u2i]]
+    if which == 'p5s2':
+        return full, [2, 2, 2, 2, 2]
+    if which == 'p3mixed':
+        return [[u2i, f(u2i)], [f(t2i), t2i, f(u2i)], [t2u]], [2, 3, 1]
+    if which == 'p3deep':
+        # no 1-step channel: with num_heads > 1 the reference's 1-step GAT channel emits
+        # repr_dim*heads columns (models/peagat.py:16) and torch.cat at models/base.py:196 fails
+        return [[u2i, f(u2i)], [f(t2i), t2i, f(u2i)], [t2u, u2i]], [2, 3, 2]
+    raise ValueError(which)
+
+
+def make_case(mods, name, kind, which, heads, channel_aggr, seed, entity_aware=False):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    n, blocks, rel = tiny_hin(seed)
+    mpl, steps = metapaths(rel, which)
+    ModelBase = {'gat': mods['peagat'].PEAGATRecsysModel, 'gcn': mods['peagcn'].PEAGCNRecsysModel,
+                 'sage': mods['peasage'].PEASageRecsysModel}[kind]
+
+    class PEAModel(ModelBase):                  # name starts with 'PEA' -> eval(metapath_idx) honoured
+        def update_graph_input(self, dataset):  # (models/base.py:91)
+            return mpl
+
+    kw = dict(entity_aware=entity_aware, entity_aware_coff=0.1, meta_path_steps=steps,
+              if_use_features=False, channel_aggr=channel_aggr, dataset={'num_nodes': n},
+              num_nodes=n, emb_dim=32, hidden_size=24, repr_dim=16, num_heads=heads, dropout=0)
+    model = PEAModel(**kw)
+    # trained-like magnitudes and NON-ZERO biases (fresh init has bias == 0)
+    with torch.no_grad():
+        for pname, p in model.named_parameters():
+            if pname.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+            elif pname != 'x':
+                p.mul_(1.5)
+    fx = {}
+    sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        fx['param/' + k] = v
+    for p, eil in enumerate(mpl):
+        for s, ei in enumerate(eil):
+            fx['edge/%d/%d' % (p, s)] = ei.numpy()
+    meta = dict(kind=kind, heads=heads, channel_aggr=channel_aggr, steps=steps, num_nodes=n,
+                emb_dim=32, hidden_size=24, repr_dim=16, entity_aware=entity_aware,
+                gcn_deg_from='row', seed=seed)
+
+    # per-channel outputs straight from the reference channel loop
+    with torch.no_grad():
+        for p, ch in enumerate(model.pea_channels):
+            fx['out/channel/%d' % p] = ch(model.x, mpl[p]).numpy()
+        # eval(): cached_repr, with and without ablation mask (models/base.py:88-96,194-195)
+        model.eval()
+        fx['out/repr'] = model.cached_repr.numpy().copy()
+        model.eval(1)
+        fx['out/repr_mask1'] = model.cached_repr.numpy().copy()
+        model.eval()
+        rng = np.random.default_rng(seed + 1)
+        B = 64
+        u = rng.integers(*blocks['u'], size=B)
+        ip = rng.integers(*blocks['i'], size=B)
+        ineg = rng.integers(*blocks['i'], size=B)
+        batch = np.stack([u, ip, ineg], axis=1).astype(np.int64)
+        bt = torch.from_numpy(batch)
+        fx['in/batch'] = batch
+        fx['out/pos'] = model.predict(bt[:, 0], bt[:, 1]).numpy().reshape(-1)
+        fx['out/neg'] = model.predict(bt[:, 0], bt[:, 2]).numpy().reshape(-1)
+        fx['out/loss_eval'] = np.float32(model.loss(bt).item())
+    # training-mode loss recomputes the forward (models/base.py:44-45)
+    model.train()
+    if entity_aware:
+        ent = rng.integers(0, n, size=(B, 6))
+        mask = rng.integers(0, 2, size=(B, 2))
+        batch9 = np.concatenate([batch, ent[:, 0:2], mask[:, 0:1], ent[:, 2:4], mask[:, 1:2]], axis=1)
+        fx['in/batch9'] = batch9.astype(np.int64)
+        fx['out/loss_train'] = np.float32(model.loss(torch.from_numpy(batch9.astype(np.int64))).item())
+    else:
+        fx['out/loss_train'] = np.float32(model.loss(bt).item())
+    fx['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
+    print(name, 'N=%d' % n, 'loss_train=%.6f' % float(fx['out/loss_train']),
+          '%.0f kB' % (os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e3))
+
+
+def make_rec_utils(mods):
+    ru = mods['rec_utils']
+    rng = np.random.default_rng(7)
+    cases = []
+    for pos_rank in [0, 3, 4, 5, 9, 10, 19, 20, 57, 99]:
+        hv = np.zeros(100, dtype=bool)
+        hv[pos_rank] = True
+        pos = rng.normal(size=1).astype(np.float32)
+        neg = rng.normal(size=99).astype(np.float32)
+        cases.append(dict(hit_vec=hv.astype(int).tolist(), hit=[int(v) for v in ru.hit(hv)],
+                          ndcg=[float(v) for v in ru.ndcg(hv)],
+                          pos=pos.tolist(), neg=neg.tolist(), auc=float(ru.auc(pos, neg))))
+    with open(os.path.join(OUT, 'rec_utils.json'), 'w') as f:
+        json.dump(cases, f)
+    print('rec_utils.json', len(cases), 'cases')
+
+
+def make_rng_streams():
+    """Legacy host RNG streams the reference's negative sampling draws from
+    (datasets/movielens.py:920-937, solvers.py:29,123-127); stable across numpy versions."""
+    out = {}
+    np.random.seed(2020)
+    out['randint_608_2729_x32'] = np.random.randint(low=608, high=608 + 2121, size=(32, 1)).reshape(-1).tolist()
+    np.random.seed(2020)
+    out['choice_100_200_x5'] = np.random.choice(list(range(100, 200)), size=(5,)).tolist()
+    random.seed(2020)
+    out['choices_100_200_k4'] = random.choices(list(range(100, 200)), k=4)
+    # survey-recorded known answers as a cross-check of this container
+    assert out['randint_608_2729_x32'][:8] == [1472, 1000, 2269, 2584, 765, 1168, 1792, 1528]
+    assert out['choice_100_200_x5'] == [196, 108, 167, 167, 191]
+    assert out['choices_100_200_k4'] == [161, 117, 176, 194]
+    with open(os.path.join(OUT, 'rng_streams.json'), 'w') as f:
+        json.dump(out, f)
+    print('rng_streams.json ok')
+
+
+def make_checkpoint_manifest():
+    """Key / shape / dtype / checksum manifest of the six shipped checkpoints.
+    Read with weights_only=True (nothing in the pickle is executed)."""
+    root = os.path.join(REF, 'experiments', 'checkpoint', 'weights', 'Movielenslatest-small')
+    import numpy._core.multiarray as ncm
+    allow = [(ncm._reconstruct, 'numpy.core.multiarray._reconstruct'),
+             (ncm.scalar, 'numpy.core.multiarray.scalar'),
+             np.ndarray, np.dtype, type(np.dtype(np.float64))]
+    man = {}
+    for model in ('PEAGAT', 'PEAGCN', 'PEASage'):
+        base = os.path.join(root, model, 'BPR')
+        for d in sorted(os.listdir(base)):
+            path = os.path.join(base, d, 'run_1', 'latest.pkl')
+            with torch.serialization.safe_globals(allow):
+                ck = torch.load(path, map_location='cpu', weights_only=True)
+            sd = ck['model_states']['model']
+            ea = "'entity_aware': True" in d
+            man['%s/entity_aware=%s' % (model, ea)] = dict(
+                epoch=int(ck['epoch']),
+                keys={k: dict(shape=list(v.shape), dtype=str(v.dtype),
+                              sum=float(v.double().sum()), abs_sum=float(v.double().abs().sum()))
+                      for k, v in sd.items()})
+    with open(os.path.join(OUT, 'checkpoint_manifest.json'), 'w') as f:
+        json.dump(man, f, indent=0)
+    print('checkpoint_manifest.json', {k: len(v['keys']) for k, v in man.items()})
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    mods = load_reference_models()
+    make_case(mods, 'pea_gat_p5s2_h1_att', 'gat', 'p5s2', 1, 'att', 2020)
+    make_case(mods, 'pea_gat_p3deep_h2_att', 'gat', 'p3deep', 2, 'att', 2021)
+    make_case(mods, 'pea_gat_p3mixed_h1_att', 'gat', 'p3mixed', 1, 'att', 2028)
+    make_case(mods, 'pea_gat_p5s2_h1_mean', 'gat', 'p5s2', 1, 'mean', 2022)
+    make_case(mods, 'pea_gcn_p5s2_att', 'gcn', 'p5s2', 1, 'att', 2023)
+    make_case(mods, 'pea_gcn_p3mixed_mean', 'gcn', 'p3mixed', 1, 'mean', 2024)
+    make_case(mods, 'pea_sage_p5s2_att', 'sage', 'p5s2', 1, 'att', 2025)
+    make_case(mods, 'pea_sage_p3mixed_att', 'sage', 'p3mixed', 1, 'att', 2026)
+    make_case(mods, 'pea_gat_p5s2_h1_att_ea', 'gat', 'p5s2', 1, 'att', 2027, entity_aware=True)
+    make_rec_utils(mods)
+    make_rng_streams()
+    make_checkpoint_manifest()
