@@ -1,0 +1,103 @@
+"""ctypes binding of libpeahip.so (C ABI: include/peahip.h).
+
+The product path has NO fallback: if the HIP library is missing or no gfx950 device is visible, every
+compute entry point raises.  (CPU parity checking lives in oracle/, which this package never imports.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libpeahip.so')
+
+PEA_OK = 0
+KIND_GAT, KIND_GCN, KIND_SAGE = 0, 1, 2
+PLAN_SELF_LOOPS = 1
+FUSE_ATT, FUSE_MEAN = 0, 1
+
+_ERR_NAMES = {-1: 'bad argument', -2: 'id out of range', -3: 'HIP runtime error', -4: 'workspace too small',
+              -5: 'no gfx950 device'}
+
+
+class PeaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('peahip error %d (%s): %s' % (code, _ERR_NAMES.get(code, '?'), msg))
+        self.code = code
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [('kind', C.c_int), ('num_channels', C.c_int), ('steps', C.POINTER(C.c_int)),
+                ('relation_of', C.POINTER(C.c_int)), ('emb_dim', C.c_int), ('hidden_size', C.c_int),
+                ('repr_dim', C.c_int), ('heads', C.c_int), ('fuse_mode', C.c_int),
+                ('gcn_deg_from_col', C.c_int), ('negative_slope', C.c_float)]
+
+
+# every symbol include/peahip.h declares: name -> (restype, argtypes)
+_vp, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+SIGNATURES = {
+    'pea_version': (C.c_char_p, []),
+    'pea_last_error': (C.c_char_p, []),
+    'pea_device_count': (_int, []),
+    'pea_plan_create': (_int, [_i64, _int, C.POINTER(_vp), C.POINTER(_i64), _int, _int, _int, _int, _vp, C.POINTER(_vp)]),
+    'pea_plan_destroy': (_int, [_vp]),
+    'pea_plan_relation_info': (_int, [_vp, _int, C.POINTER(_i64)]),
+    'pea_plan_export_csr': (_int, [_vp, _int, _vp, _vp, _vp]),
+    'pea_model_create': (_int, [_vp, C.POINTER(ModelDesc), C.POINTER(_vp)]),
+    'pea_model_destroy': (_int, [_vp]),
+    'pea_model_workspace_bytes': (_sz, [_vp]),
+    'pea_model_params_per_layer': (_int, [_vp]),
+    'pea_model_forward': (_int, [_vp, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
+    'pea_model_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    'pea_conv_workspace_bytes': (_sz, [_vp, _int, _int, _int, _int, _int]),
+    'pea_gat_conv': (_int, [_vp, _int, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, C.c_float, _int, _vp, _i64, _vp, _sz, _vp]),
+    'pea_gcn_conv': (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _int, _int, _vp, _i64, _vp, _sz, _vp]),
+    'pea_sage_conv': (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _int, _vp, _i64, _vp, _sz, _vp]),
+    'pea_fuse': (_int, [_i64, _int, _int, _vp, _i64, C.POINTER(_int), _vp, _int, _int, _vp, _vp]),
+    'pea_bpr_workspace_bytes': (_sz, [_i64]),
+    'pea_bpr_score': (_int, [_i64, _int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pea_predict': (_int, [_i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pea_rank_eval': (_int, [_i64, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library and types every entry point.  Raises if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(or make -C graph_recsys_benchmark_amd/csrc); there is no CPU fallback' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().pea_last_error().decode()
+
+
+def check(rc):
+    if rc != PEA_OK:
+        raise PeaError(rc, last_error())
+
+
+def require_device():
+    lib = load()
+    if lib.pea_device_count() <= 0:
+        raise PeaError(-5, 'no gfx950 (MI355X) device visible; the HIP path has no CPU fallback')
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

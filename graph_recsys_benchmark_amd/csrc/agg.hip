@@ -1,0 +1,399 @@
+// Neighbour aggregation over destination-sorted CSR for gfx950 (wave64).
+//
+// Replaces, per conv layer, PyG 1.5.0's  index_select -> message -> scatter  pipeline
+// (reference call site graph_recsys_benchmark/models/base.py:138-139):
+//   AGG_GAT  : leaky_relu logits, per-target softmax (online, single pass), weighted sum, +bias, relu
+//   AGG_GCN  : sum_j dinv[j]*dinv[i]*h_j, +bias, relu
+//   AGG_MEAN : mean_j x_j (SAGE; the linear terms follow in the GEMM)
+// No [M,F] temporaries, no float atomics: every output row is produced by one wave (or by a
+// fixed-order merge of its hub chunks), so results are bitwise reproducible run to run.
+//
+// Thread mapping: a row chunk of W <= 256 fp32 columns is covered by G = 4..64 lanes x float4.
+//   short rows  : one G-lane subgroup per destination row (64/G rows per wave), edges in sequence
+//   long rows   : one wave per row (or per <=512-edge chunk of a hub row); the wave loads 64 source
+//                 ids coalesced, the 64/G subgroups take them round-robin, partial states are merged
+//                 with xor shuffles
+//   hub rows    : chunks write (m, s, acc) records; a merge kernel folds them in chunk order
+#include "common.h"
+
+namespace pea {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kNegBig = -3.0e38f;  // finite "minus infinity" for the running max (no inf-inf NaNs)
+
+struct AggLaunch {
+    int n_groups;
+    int blk_start[kMaxAggGroups + 1];
+    AggGroup g[kMaxAggGroups];
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 fma4(float w, float4 h, float4 a) {
+    return make_float4(fmaf(w, h.x, a.x), fmaf(w, h.y, a.y), fmaf(w, h.z, a.z), fmaf(w, h.w, a.w));
+}
+__device__ __forceinline__ float4 scale4(float4 a, float f) { return make_float4(a.x * f, a.y * f, a.z * f, a.w * f); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
+    return make_float4(__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m), __shfl_xor(v.w, m));
+}
+
+// Running softmax-weighted sum for one attention group: value = acc / s with weights exp(e - m).
+struct Soft {
+    float m, s;
+    float4 acc;
+    __device__ __forceinline__ void init() { m = kNegBig; s = 0.f; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
+    // one exp per edge: x = exp(-|e - m|) rescales either the state (new max) or the newcomer
+    __device__ __forceinline__ void push(float e, float4 h) {
+        const float d = e - m;
+        const float x = __expf(-fabsf(d));
+        const bool up = d > 0.f;
+        const float fs = up ? x : 1.f;   // factor on the old state
+        const float p = up ? 1.f : x;    // weight of the new edge
+        m = up ? e : m;
+        s = fmaf(s, fs, p);
+        acc.x = fmaf(acc.x, fs, p * h.x);
+        acc.y = fmaf(acc.y, fs, p * h.y);
+        acc.z = fmaf(acc.z, fs, p * h.z);
+        acc.w = fmaf(acc.w, fs, p * h.w);
+    }
+    __device__ __forceinline__ void merge(float m2, float s2, float4 a2) {
+        const float mn = fmaxf(m, m2);
+        const float f1 = __expf(m - mn), f2 = __expf(m2 - mn);
+        s = s * f1 + s2 * f2;
+        acc = add4(scale4(acc, f1), scale4(a2, f2));
+        m = mn;
+    }
+};
+
+__device__ __forceinline__ float leaky(float a, float slope) { return a > 0.f ? a : a * slope; }
+
+__device__ __forceinline__ int find_group(const AggLaunch &L) {
+    int g = 0;
+    while (g + 1 < L.n_groups && (int)blockIdx.x >= L.blk_start[g + 1]) ++g;
+    return g;
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish_row(const AggGroup &P, int row, int c4, int deg, Soft st, float4 sum) {
+    float4 o;
+    if (MODE == AGG_GAT) {
+        const float inv = 1.0f / (st.s + 1e-16f);
+        o = scale4(st.acc, inv);
+    } else if (MODE == AGG_GCN) {
+        o = sum;
+    } else {
+        const float inv = 1.0f / (float)(deg < 1 ? 1 : deg);
+        o = scale4(sum, inv);
+    }
+    if (P.bias) o = add4(o, ld4(P.bias + c4));
+    if (P.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    st4(P.out + (size_t)row * P.ld_out + c4, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// short rows: one G-lane subgroup per destination row
+// ------------------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / G) + (int)threadIdx.x / G;
+    const int sl = (int)threadIdx.x % G;
+    const bool valid = item < P.n_short;
+    const int row = valid ? P.short_rows[item] : 0;
+    const bool active = valid && sl * 4 < P.W;
+    const int c4 = active ? sl * 4 : 0;
+    const int beg = P.rowptr[row];
+    const int end = valid ? P.rowptr[row + 1] : beg;
+    const float *feat = P.feat + c4;
+
+    Soft st;
+    st.init();
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int kk = 0;
+    float a_d = 0.f, di = 0.f;
+    if (MODE == AGG_GAT) {
+        kk = 2 * (c4 / P.F);
+        a_d = P.a_dst[(size_t)row * P.ld_a + kk];
+    } else if (MODE == AGG_GCN) {
+        di = P.dinv[row];
+    }
+    for (int e = beg; e < end; ++e) {
+        const int j = P.col[e];
+        const float4 h = ld4(feat + (size_t)j * P.ld_feat);
+        if (MODE == AGG_GAT) {
+            const float a = P.a_src[(size_t)j * P.ld_a + kk];
+            st.push(leaky(a + a_d, P.neg_slope), h);
+        } else if (MODE == AGG_GCN) {
+            sum = fma4(P.dinv[j] * di, h, sum);
+        } else {
+            sum = add4(sum, h);
+        }
+    }
+    if (P.self_loop) {
+        const float4 h = ld4(feat + (size_t)row * P.ld_feat);
+        if (MODE == AGG_GAT) {
+            const float a = P.a_src[(size_t)row * P.ld_a + kk];
+            st.push(leaky(a + a_d, P.neg_slope), h);
+        } else if (MODE == AGG_GCN) {
+            sum = fma4(di * di, h, sum);
+        }
+    }
+    if (active) finish_row<MODE>(P, row, c4, end - beg, st, sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// long rows and hub chunks: one wave per item
+// ------------------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
+    constexpr int NSG = kWave / G;
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int wave = (int)threadIdx.x / kWave;
+    const int lane = (int)threadIdx.x % kWave;
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + wave;
+    if (item >= P.n_long) return;  // wave-uniform
+    const LongItem it = P.long_items[item];
+    const int sub = lane / G, sl = lane % G;
+    const bool active = sl * 4 < P.W;
+    const int c4 = active ? sl * 4 : 0;
+    const float *feat = P.feat + c4;
+    const int row = it.row;
+
+    Soft st;
+    st.init();
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int kk = 0;
+    float a_d = 0.f, di = 0.f;
+    if (MODE == AGG_GAT) {
+        kk = 2 * (c4 / P.F);
+        a_d = P.a_dst[(size_t)row * P.ld_a + kk];
+    } else if (MODE == AGG_GCN) {
+        di = P.dinv[row];
+    }
+    for (int base = it.beg; base < it.end; base += kWave) {
+        const int my = base + lane;
+        const int src = my < it.end ? P.col[my] : -1;
+        const int cnt = min(kWave, it.end - base);
+#pragma unroll 4
+        for (int t = 0; t < cnt; t += NSG) {
+            const int j = __shfl(src, t + sub);
+            const bool ok = j >= 0;
+            const int jj = ok ? j : row;
+            const float4 h = ld4(feat + (size_t)jj * P.ld_feat);
+            if (MODE == AGG_GAT) {
+                const float a = P.a_src[(size_t)jj * P.ld_a + kk];
+                if (ok) st.push(leaky(a + a_d, P.neg_slope), h);
+            } else if (MODE == AGG_GCN) {
+                const float w = ok ? P.dinv[jj] * di : 0.f;
+                sum = fma4(w, h, sum);
+            } else {
+                if (ok) sum = add4(sum, h);
+            }
+        }
+    }
+    // fold the NSG subgroup states (xor butterfly: every lane ends with the same value)
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) {
+        if (MODE == AGG_GAT) {
+            const float m2 = __shfl_xor(st.m, off), s2 = __shfl_xor(st.s, off);
+            const float4 a2 = shfl_xor4(st.acc, off);
+            st.merge(m2, s2, a2);
+        } else {
+            sum = add4(sum, shfl_xor4(sum, off));
+        }
+    }
+    if (it.slot >= 0) {  // hub chunk: write the partial record, the merge kernel finishes the row
+        if (sub == 0 && active) {
+            const int nk = P.W / P.F;
+            float *rec = P.partial + (size_t)it.slot * (size_t)(P.W + 2 * nk);
+            if (MODE == AGG_GAT) {
+                st4(rec + c4, st.acc);
+                if (c4 % P.F == 0) {
+                    rec[P.W + kk] = st.m;
+                    rec[P.W + kk + 1] = st.s;
+                }
+            } else {
+                st4(rec + c4, sum);
+            }
+        }
+        return;
+    }
+    if (P.self_loop) {
+        const float4 h = ld4(feat + (size_t)row * P.ld_feat);
+        if (MODE == AGG_GAT) {
+            const float a = P.a_src[(size_t)row * P.ld_a + kk];
+            st.push(leaky(a + a_d, P.neg_slope), h);
+        } else if (MODE == AGG_GCN) {
+            sum = fma4(di * di, h, sum);
+        }
+    }
+    if (sub == 0 && active) finish_row<MODE>(P, row, c4, it.end - it.beg, st, sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hub rows: fold the chunk records in chunk order, add the self loop, finish
+// ------------------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
+    constexpr int NSG = kWave / G;
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int wave = (int)threadIdx.x / kWave;
+    const int lane = (int)threadIdx.x % kWave;
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + wave;
+    if (item >= P.n_hub) return;
+    const int row = P.hub_rows[item];
+    const int first = P.hub_first[item], count = P.hub_count[item];
+    const int sub = lane / G, sl = lane % G;
+    const bool active = sl * 4 < P.W;
+    const int c4 = active ? sl * 4 : 0;
+    const int nk = P.W / P.F;
+    const size_t rec_sz = (size_t)(P.W + 2 * nk);
+    const int kk = 2 * (c4 / P.F);
+
+    Soft st;
+    st.init();
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = sub; c < count; c += NSG) {
+        const float *rec = P.partial + (size_t)(first + c) * rec_sz;
+        const float4 a = ld4(rec + c4);
+        if (MODE == AGG_GAT) {
+            st.merge(rec[P.W + kk], rec[P.W + kk + 1], a);
+        } else {
+            sum = add4(sum, a);
+        }
+    }
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) {
+        if (MODE == AGG_GAT) {
+            const float m2 = __shfl_xor(st.m, off), s2 = __shfl_xor(st.s, off);
+            const float4 a2 = shfl_xor4(st.acc, off);
+            st.merge(m2, s2, a2);
+        } else {
+            sum = add4(sum, shfl_xor4(sum, off));
+        }
+    }
+    const float *feat = P.feat + c4;
+    if (P.self_loop) {
+        const float4 h = ld4(feat + (size_t)row * P.ld_feat);
+        if (MODE == AGG_GAT) {
+            const float a_d = P.a_dst[(size_t)row * P.ld_a + kk];
+            const float a = P.a_src[(size_t)row * P.ld_a + kk];
+            st.push(leaky(a + a_d, P.neg_slope), h);
+        } else if (MODE == AGG_GCN) {
+            const float di = P.dinv[row];
+            sum = fma4(di * di, h, sum);
+        }
+    }
+    const int deg = P.rowptr[row + 1] - P.rowptr[row];
+    if (sub == 0 && active) finish_row<MODE>(P, row, c4, deg, st, sum);
+}
+
+int lanes_for(int W) {
+    int g = 4;
+    while (g * 4 < W) g <<= 1;
+    return g;
+}
+
+template <int G, int MODE>
+int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
+    AggLaunch L;
+    // short
+    L.n_groups = 0;
+    int blocks = 0;
+    for (int i = 0; i < n_sel; ++i) {
+        const AggGroup &g = base.g[sel[i]];
+        if (g.n_short <= 0) continue;
+        L.blk_start[L.n_groups] = blocks;
+        L.g[L.n_groups++] = g;
+        blocks += (g.n_short + (kBlock / G) - 1) / (kBlock / G);
+    }
+    L.blk_start[L.n_groups] = blocks;
+    if (blocks > 0) {
+        hipLaunchKernelGGL((agg_short_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        PEA_HIP(hipGetLastError());
+    }
+    // long + hub chunks
+    L.n_groups = 0;
+    blocks = 0;
+    for (int i = 0; i < n_sel; ++i) {
+        const AggGroup &g = base.g[sel[i]];
+        if (g.n_long <= 0) continue;
+        L.blk_start[L.n_groups] = blocks;
+        L.g[L.n_groups++] = g;
+        blocks += (g.n_long + 3) / 4;
+    }
+    L.blk_start[L.n_groups] = blocks;
+    if (blocks > 0) {
+        hipLaunchKernelGGL((agg_long_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        PEA_HIP(hipGetLastError());
+    }
+    // hub merge
+    L.n_groups = 0;
+    blocks = 0;
+    for (int i = 0; i < n_sel; ++i) {
+        const AggGroup &g = base.g[sel[i]];
+        if (g.n_hub <= 0) continue;
+        L.blk_start[L.n_groups] = blocks;
+        L.g[L.n_groups++] = g;
+        blocks += (g.n_hub + 3) / 4;
+    }
+    L.blk_start[L.n_groups] = blocks;
+    if (blocks > 0) {
+        hipLaunchKernelGGL((agg_merge_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        PEA_HIP(hipGetLastError());
+    }
+    return PEA_OK;
+}
+
+template <int MODE>
+int launch_mode(const AggLaunch &base, hipStream_t stream) {
+    for (int G = 4; G <= 64; G <<= 1) {
+        int sel[kMaxAggGroups], n = 0;
+        for (int i = 0; i < base.n_groups; ++i)
+            if (lanes_for(base.g[i].W) == G) sel[n++] = i;
+        if (!n) continue;
+        switch (G) {
+            case 4: PEA_TRY((launch_for_g<4, MODE>(base, sel, n, stream))); break;
+            case 8: PEA_TRY((launch_for_g<8, MODE>(base, sel, n, stream))); break;
+            case 16: PEA_TRY((launch_for_g<16, MODE>(base, sel, n, stream))); break;
+            case 32: PEA_TRY((launch_for_g<32, MODE>(base, sel, n, stream))); break;
+            default: PEA_TRY((launch_for_g<64, MODE>(base, sel, n, stream))); break;
+        }
+    }
+    return PEA_OK;
+}
+
+}  // namespace
+
+size_t partial_record_floats(int W, int F) { return (size_t)W + 2 * (size_t)(W / F); }
+
+int launch_aggregate(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream) {
+    PEA_REQUIRE(n_groups >= 0 && n_groups <= kMaxAggGroups, PEA_ERR_ARG, "aggregate: %d groups (max %d)",
+                n_groups, kMaxAggGroups);
+    AggLaunch base;
+    base.n_groups = n_groups;
+    for (int i = 0; i < n_groups; ++i) {
+        const AggGroup &g = groups[i];
+        PEA_REQUIRE(g.W > 0 && g.W <= 256 && g.W % 4 == 0, PEA_ERR_ARG,
+                    "aggregate: group width %d must be a multiple of 4 in (0, 256]", g.W);
+        PEA_REQUIRE(g.F > 0 && g.F % 4 == 0 && g.W % g.F == 0, PEA_ERR_ARG,
+                    "aggregate: head width %d must be a multiple of 4 dividing %d", g.F, g.W);
+        PEA_REQUIRE(g.ld_feat % 4 == 0 && g.ld_out % 4 == 0, PEA_ERR_ARG,
+                    "aggregate: row strides must be multiples of 4 floats");
+        PEA_REQUIRE(g.n_hub == 0 || g.partial != nullptr, PEA_ERR_ARG, "aggregate: hub rows need a partial buffer");
+        base.g[i] = g;
+    }
+    switch (mode) {
+        case AGG_GAT: return launch_mode<AGG_GAT>(base, stream);
+        case AGG_GCN: return launch_mode<AGG_GCN>(base, stream);
+        default: return launch_mode<AGG_MEAN>(base, stream);
+    }
+}
+
+}  // namespace pea

@@ -1,0 +1,163 @@
+// Internal declarations shared by the peahip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/peahip.h"
+
+namespace pea {
+
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+#define PEA_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pea::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,                 \
+                           hipGetErrorString(e_));                                             \
+            return PEA_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define PEA_REQUIRE(cond, code, ...)                                                           \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            pea::set_error(__VA_ARGS__);                                                       \
+            return (code);                                                                     \
+        }                                                                                      \
+    } while (0)
+
+#define PEA_TRY(expr)                                                                          \
+    do {                                                                                       \
+        int rc_ = (expr);                                                                      \
+        if (rc_ != PEA_OK) return rc_;                                                         \
+    } while (0)
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kShortDeg = 32;      // rows with <= this many kept edges go to the row-per-subgroup kernel
+constexpr int kChunk = 512;        // hub rows are cut into chunks of at most this many edges
+
+// One work item of the row-per-wave kernel: edges [beg, end) of `row`; slot < 0 writes the output row,
+// slot >= 0 writes a partial record (hub chunk) that the merge kernel folds in chunk order.
+struct LongItem {
+    int row, beg, end, slot;
+};
+
+struct Relation {
+    int64_t e_in = 0;       // COO edges handed over
+    int64_t e_kept = 0;     // after self-loop removal (if the plan does that)
+    int max_deg = 0;
+    int *rowptr = nullptr;  // device [N+1]
+    int *col = nullptr;     // device [e_kept] source ids, destination-sorted, stable
+    float *dinv_row = nullptr, *dinv_col = nullptr;  // device [N], GCN deg^-1/2 (lazy)
+    // work lists (device), restricted to the rows this rank owns
+    int *short_rows = nullptr;
+    int n_short = 0;
+    LongItem *long_items = nullptr;
+    int n_long = 0;
+    int *hub_rows = nullptr, *hub_first = nullptr, *hub_count = nullptr;  // per hub row: first slot, #chunks
+    int n_hub = 0, n_slots = 0;
+    int64_t rows_owned = 0, edges_owned = 0;
+};
+
+}  // namespace pea
+
+struct pea_plan {
+    int64_t N = 0;
+    int flags = 0;
+    int shard_rank = 0, shard_world = 1, shard_tile = 256;
+    std::vector<pea::Relation> rels;
+    int max_slots = 0;  // max hub chunks over relations (sizes the partial workspace)
+};
+
+namespace pea {
+
+int ensure_dinv(pea_plan *plan, int rel, bool from_col, hipStream_t stream);
+
+// ---------------------------------------------------------------- aggregation (agg.hip)
+enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2 };
+
+// One horizontal group: C channel-heads of width F that share a relation, columns contiguous.
+struct AggGroup {
+    const int *rowptr;
+    const int *col;
+    const int *short_rows;
+    const LongItem *long_items;
+    const int *hub_rows, *hub_first, *hub_count;
+    int n_short, n_long, n_hub;
+    const float *feat;   // gather source; row j at feat + j*ld_feat
+    const float *a_src;  // GAT: a_src[j*ld_a + k]
+    const float *a_dst;  // GAT: a_dst[i*ld_a + k]
+    const float *dinv;   // GCN
+    const float *bias;   // [W] or null
+    float *out;          // row i at out + i*ld_out
+    float *partial;      // hub partial records
+    int ld_feat, ld_a, ld_out;
+    int W;               // columns of this group (multiple of 4, <= 256)
+    int F;               // columns per attention group (GAT), W % F == 0
+    int relu;
+    int self_loop;       // add the i->i message (GAT/GCN)
+    float neg_slope;
+};
+
+constexpr int kMaxAggGroups = 16;
+int launch_aggregate(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream);
+size_t partial_record_floats(int W, int F);
+
+// ---------------------------------------------------------------- dense transform (gemm.hip)
+struct GemmSegment {   // output columns [c0, c1) of the job go to dst[row*ld + (c - c0)]
+    int c0, c1;
+    float *dst;
+    int ld;
+    int relu;
+};
+constexpr int kMaxSegments = 4;
+struct GemmJob {
+    const float *A1;  // [N, K1] row stride lda1
+    const float *A2;  // optional second source [N, K2] (SAGE root term), K = K1 + K2
+    int lda1, lda2, K1, K2;
+    const float *B;   // packed [K1+K2][ldb] k-major
+    int ldb;
+    int n_out;        // columns (multiple of 4)
+    const float *bias;  // [n_out] or null (packed alongside B)
+    int n_seg;
+    GemmSegment seg[kMaxSegments];
+};
+int launch_gemm(const GemmJob &job, const int *rows, int64_t n_rows, hipStream_t stream);
+
+// weight packing: produces the k-major extended weight blocks the GEMM consumes
+struct PackJob {
+    int kind;            // PEA_KIND_*
+    const float *w0;     // GAT lin.weight [HF,in] | GCN weight [in,F] | SAGE lin_rel.weight [F,in]
+    const float *w1;     // GAT att_i [HF]         |  -                | SAGE lin_root.weight [F,in]
+    const float *w2;     // GAT att_j [HF]         |  -                |  -
+    const float *w3;     // bias source [HF] (GAT bias | GCN bias | SAGE lin_rel.bias), may be null -> zeros
+    float *B;            // destination block start (column offset already applied), row stride ldb
+    float *bias;         // destination bias block [HF]
+    int ldb;
+    int in, HF, F;       // input width, output width, width per attention group
+    int a_col;           // GAT: column (relative to B) where this layer's 2*heads attention columns start
+    int zero_col, zero_n;  // padding columns (relative to B) to clear in every k row
+};
+int launch_pack(const PackJob *jobs_host, int n_jobs, hipStream_t stream);
+
+// ---------------------------------------------------------------- fusion / scoring (fuse_score.hip)
+constexpr int kMaxChannels = 64;
+struct ChanCols {
+    int c[kMaxChannels];
+};
+int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const ChanCols &col_of_channel,
+                const float *att, int masked, int mode, const int *rows, int64_t n_rows, float *out,
+                float *out_stack, hipStream_t stream);
+
+int model_forward(pea_model *m, const float *const *params, const float *x, int64_t ldx, const float *att,
+                  int masked, float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x,
+                  int relu_last, hipStream_t stream);
+
+}  // namespace pea

@@ -1,0 +1,660 @@
+// Schedule of one PEA forward on gfx950: the per-metapath channel loop of
+// graph_recsys_benchmark/models/base.py:129-140 (PEABaseChannel.forward) run for all P channels of
+// models/base.py:191-193, then the fusion of models/base.py:196-203 -- as a fixed sequence of launches on
+// one stream (capturable in a hipGraph by the caller; nothing here synchronises or allocates).
+//
+// The reference runs P x S independent conv calls.  Here the work is regrouped per LEVEL (step index):
+//   - all channels of a level that read the same input share one GEMM job (level 0: every channel
+//     reads x, models/base.py:192);
+//   - channels of a level that aggregate over the same relation are fused HORIZONTALLY: their feature
+//     columns sit side by side, so the relation's index array is read once and a gathered row is one
+//     contiguous run (7 of the 9 MovieLens metapaths end in flip(user2item),
+//     utils/general_utils.py:300-307 / 335-343);
+//   - the GAT attention projections ride along as extra GEMM columns (gemm.hip).
+// Buffers (row-major fp32, row strides multiples of 4 floats), per level s:
+//   GAT/GCN : T_s [N, sum HF] transformed features (gather source), A_s [N, 2*sum heads] (a_src, a_dst
+//             interleaved per head), O_s [N, sum HF] relu(conv) output = input of level s+1
+//   SAGE    : M_s [N, ...] neighbour means of the level's input, O_s [N, sum F]
+//   X [N, P*R]: last-layer outputs of every channel (the "stack" the fusion reads).
+#include <algorithm>
+#include <cstring>
+
+#include "common.h"
+
+namespace pea {
+
+struct Unit {  // one channel at one level
+    int p = 0, s = 0, rel = 0;
+    int in_w = 0, heads = 1, F = 0, HF = 0;
+    bool last = false;
+    int in_col = 0;    // column of the input block (level 0: 0 in x; else in O_{s-1})
+    int t_col = 0;     // column in T_s (GAT/GCN) or of its mean block in M_s (SAGE)
+    int a_k = 0;       // first attention index in A_s
+    int o_col = 0;     // column in O_s (non-last) or X (last)
+    size_t b_off = 0;  // packed weight block (floats from the pack base)
+    int ldb = 0;
+    size_t bias_off = 0;
+};
+
+struct GroupPlan {  // one aggregation group of a level
+    int rel = 0;
+    int col = 0, W = 0, F = 0;  // columns [col, col+W) of the gather source
+    int a_k = 0;                // first attention index
+    bool last = false;
+    int out_col = 0;            // column in O_s / X (GAT/GCN) or M_s (SAGE)
+    size_t bias_off = 0;        // packed bias (floats from the pack base), GAT/GCN
+    size_t partial_off = 0;     // floats from the partial base
+};
+
+struct Level {
+    std::vector<Unit> units;  // in buffer (column) order
+    std::vector<GroupPlan> groups;
+    int n_cols = 0, n_heads = 0;             // sum HF, sum heads (GAT/GCN)
+    int ld_t = 0, ld_a = 0, ld_o = 0;        // strides of T_s (or M_s), A_s, O_s
+    size_t off_t = 0, off_a = 0, off_o = 0;  // float offsets in the workspace
+    bool shared_input = false;               // level 0 of GAT/GCN: one concatenated GEMM job
+    size_t b_off = 0, bias_off = 0;          // concatenated weight block / per-level bias block
+    int ldb = 0, n_out = 0;
+};
+
+}  // namespace pea
+
+struct pea_model {
+    const pea_plan *plan = nullptr;
+    pea_model_desc d{};
+    std::vector<int> steps, relation_of;  // copies of the host arrays
+    std::vector<int> chan_first;          // index of (p,0) in relation_of
+    std::vector<pea::Level> levels;
+    int n_slots_per_layer = 0;
+    int ld_x = 0;
+    pea::ChanCols x_col{};                // column of channel p in X
+    size_t pack_floats = 0;               // workspace layout (floats): [pack | levels | X | partial]
+    size_t off_x = 0, off_partial = 0, partial_floats = 0;
+    size_t total_floats = 0;
+    int64_t messages = 0;
+    double alg_bytes = 0.0;
+    bool single_conv = false;             // pea_*_conv: any output width, X goes to the caller's buffer
+};
+
+namespace pea {
+namespace {
+
+int pad4(int v) { return (v + 3) & ~3; }
+
+int width_out(const pea_model_desc &d, int S, int s, int *heads_out) {
+    // PEA{GAT,GCN,Sage}Channel (models/peagat.py:14-21): 1 step: emb -> repr with num_heads heads;
+    // else emb -> hidden (num_heads) -> ... -> repr (1 head)
+    const bool last = s == S - 1;
+    int heads = d.kind == PEA_KIND_GAT ? d.heads : 1;
+    if (S > 1 && last) heads = 1;
+    *heads_out = heads;
+    return last ? d.repr_dim : d.hidden_size;
+}
+
+int rel_at(const pea_model *m, int p, int s) { return m->relation_of[(size_t)(m->chan_first[(size_t)p] + s)]; }
+
+int build_schedule(pea_model *m) {
+    const pea_model_desc &d = m->d;
+    const pea_plan *plan = m->plan;
+    const int P = d.num_channels;
+    const int64_t N = plan->N;
+    const bool sage = d.kind == PEA_KIND_SAGE, gat = d.kind == PEA_KIND_GAT;
+    int Smax = 0;
+    for (int p = 0; p < P; ++p) Smax = std::max(Smax, m->steps[(size_t)p]);
+    m->levels.assign((size_t)Smax, Level());
+    std::vector<int> in_w((size_t)P, d.emb_dim), in_col((size_t)P, 0);
+    int x_cols = 0;
+    size_t pack = 0, ws = 0, partial_max = 0;
+    m->messages = 0;
+    m->alg_bytes = 0.0;
+
+    for (int s = 0; s < Smax; ++s) {
+        Level &L = m->levels[(size_t)s];
+        for (int p = 0; p < P; ++p) {
+            const int S = m->steps[(size_t)p];
+            if (S <= s) continue;
+            Unit u;
+            u.p = p;
+            u.s = s;
+            u.rel = rel_at(m, p, s);
+            u.in_w = in_w[(size_t)p];
+            u.F = width_out(d, S, s, &u.heads);
+            u.HF = u.heads * u.F;
+            u.last = s == S - 1;
+            u.in_col = in_col[(size_t)p];
+            PEA_REQUIRE(u.rel >= 0 && u.rel < (int)plan->rels.size(), PEA_ERR_ARG, "model: relation index %d out of range", u.rel);
+            PEA_REQUIRE(u.in_w % 4 == 0 && u.F % 4 == 0 && u.F > 0, PEA_ERR_ARG,
+                        "model: layer widths must be positive multiples of 4 (in %d, out %d)", u.in_w, u.F);
+            PEA_REQUIRE(u.F <= 256, PEA_ERR_ARG, "model: per-head width %d > 256 is not supported", u.F);
+            L.units.push_back(u);
+        }
+        // column order: channels that aggregate over the same relation side by side
+        std::stable_sort(L.units.begin(), L.units.end(), [](const Unit &a, const Unit &b) {
+            if (a.rel != b.rel) return a.rel < b.rel;
+            if (a.last != b.last) return a.last < b.last;
+            return a.F < b.F;
+        });
+        int col = 0, ak = 0;
+        for (Unit &u : L.units) {
+            u.t_col = col;
+            u.a_k = ak;
+            col += sage ? u.in_w : u.HF;
+            ak += u.heads;
+        }
+        L.n_cols = col;
+        L.n_heads = ak;
+        L.ld_t = pad4(col);
+        L.ld_a = gat ? pad4(2 * ak) : 0;
+        // outputs of channels that continue: GAT/GCN keep the T_s column order; SAGE lays O_s out in the order the
+        // NEXT level aggregates it (same relation side by side)
+        std::vector<Unit *> cont;
+        for (Unit &u : L.units)
+            if (!u.last) cont.push_back(&u);
+        if (sage)
+            std::stable_sort(cont.begin(), cont.end(), [&](const Unit *a, const Unit *b) {
+                return rel_at(m, a->p, s + 1) < rel_at(m, b->p, s + 1);
+            });
+        int ocol = 0;
+        for (Unit *u : cont) {
+            u->o_col = sage ? ocol : u->t_col;
+            ocol += u->HF;
+            in_w[(size_t)u->p] = u->HF;
+            in_col[(size_t)u->p] = u->o_col;
+        }
+        L.ld_o = sage ? pad4(ocol) : L.ld_t;
+        for (Unit &u : L.units) {
+            if (!u.last) continue;
+            u.o_col = x_cols;
+            m->x_col.c[u.p] = x_cols;
+            x_cols += u.HF;
+            PEA_REQUIRE(m->single_conv || u.HF == d.repr_dim, PEA_ERR_ARG,
+                        "model: channel %d ends %d columns wide but repr_dim is %d (a 1-step GAT channel with "
+                        "num_heads > 1 cannot be stacked; the reference fails at models/base.py:196 too)",
+                        u.p, u.HF, d.repr_dim);
+        }
+        // packed weights + biases
+        L.shared_input = !sage && s == 0;
+        if (L.shared_input) {
+            L.n_out = pad4(L.n_cols + (gat ? 2 * L.n_heads : 0));
+            L.ldb = L.n_out;
+            L.b_off = pack;
+            pack += (size_t)d.emb_dim * (size_t)L.ldb;
+            for (Unit &u : L.units) {
+                u.b_off = L.b_off + (size_t)u.t_col;
+                u.ldb = L.ldb;
+            }
+        } else {
+            for (Unit &u : L.units) {
+                const int K = sage ? 2 * u.in_w : u.in_w;
+                u.ldb = pad4(u.HF + (gat ? 2 * u.heads : 0));
+                u.b_off = pack;
+                pack += (size_t)K * (size_t)u.ldb;
+            }
+        }
+        if (sage) {
+            for (Unit &u : L.units) {
+                u.bias_off = pack;
+                pack += (size_t)u.ldb;
+            }
+        } else {  // one bias row per level, in column order, so an aggregation group's bias is contiguous
+            L.bias_off = pack;
+            pack += (size_t)L.ld_t;
+            for (Unit &u : L.units) u.bias_off = L.bias_off + (size_t)u.t_col;
+        }
+        // aggregation groups
+        size_t partial = 0;
+        size_t i = 0;
+        if (sage) {
+            int mcol = 0;
+            while (i < L.units.size()) {
+                size_t j = i;
+                while (j < L.units.size() && L.units[j].rel == L.units[i].rel) ++j;
+                int c_beg, c_end;
+                if (s == 0) {  // every channel reads x: one mean per distinct relation, shared by its channels
+                    c_beg = 0;
+                    c_end = d.emb_dim;
+                } else {
+                    c_beg = INT32_MAX;
+                    c_end = 0;
+                    for (size_t k = i; k < j; ++k) {
+                        c_beg = std::min(c_beg, L.units[k].in_col);
+                        c_end = std::max(c_end, L.units[k].in_col + L.units[k].in_w);
+                    }
+                    int covered = 0;
+                    for (size_t k = i; k < j; ++k) covered += L.units[k].in_w;
+                    PEA_REQUIRE(covered == c_end - c_beg, PEA_ERR_ARG, "model: internal layout error (SAGE run not contiguous)");
+                }
+                for (size_t k = i; k < j; ++k) L.units[k].t_col = mcol + (s == 0 ? 0 : L.units[k].in_col - c_beg);
+                for (int c = c_beg; c < c_end; c += 256) {
+                    GroupPlan g;
+                    g.rel = L.units[i].rel;
+                    g.col = c;
+                    g.W = std::min(256, c_end - c);
+                    g.F = g.W;
+                    g.out_col = mcol + (c - c_beg);
+                    g.partial_off = partial;
+                    partial += (size_t)plan->rels[(size_t)g.rel].n_slots * partial_record_floats(g.W, g.F);
+                    L.groups.push_back(g);
+                }
+                mcol += c_end - c_beg;
+                i = j;
+            }
+            L.ld_t = pad4(mcol);
+        } else {
+            while (i < L.units.size()) {
+                const Unit &u0 = L.units[i];
+                size_t j = i;
+                while (j < L.units.size() && L.units[j].rel == u0.rel && L.units[j].last == u0.last && L.units[j].F == u0.F) ++j;
+                const int c_beg = u0.t_col, c_end = L.units[j - 1].t_col + L.units[j - 1].HF;
+                const int per = std::max(1, 256 / u0.F) * u0.F;  // whole heads per group, <= 256 columns
+                for (int c = c_beg; c < c_end; c += per) {
+                    GroupPlan g;
+                    g.rel = u0.rel;
+                    g.col = c;
+                    g.W = std::min(per, c_end - c);
+                    g.F = u0.F;
+                    g.a_k = u0.a_k + (c - c_beg) / u0.F;
+                    g.last = u0.last;
+                    g.out_col = (u0.last ? u0.o_col : c_beg) + (c - c_beg);
+                    g.bias_off = L.bias_off + (size_t)c;
+                    g.partial_off = partial;
+                    partial += (size_t)plan->rels[(size_t)g.rel].n_slots * partial_record_floats(g.W, g.F);
+                    L.groups.push_back(g);
+                }
+                i = j;
+            }
+        }
+        partial_max = std::max(partial_max, partial);
+        L.off_t = ws;
+        ws += (size_t)N * (size_t)L.ld_t;
+        L.off_a = ws;
+        ws += (size_t)N * (size_t)L.ld_a;
+        L.off_o = ws;
+        ws += (size_t)N * (size_t)L.ld_o;
+        // statistics: messages and the algorithmic-byte yardstick of SURVEY.md 8(d)
+        for (const Unit &u : L.units) {
+            const Relation &R = plan->rels[(size_t)u.rel];
+            const double Nn = (double)N;
+            if (sage) {
+                m->messages += R.e_kept;
+                m->alg_bytes += (double)R.e_kept * (4.0 * u.in_w + 4.0) + 4.0 * (Nn + 1) + 4.0 * Nn * u.in_w + 4.0 * Nn * u.HF;
+            } else {
+                const double M = (double)R.e_kept + Nn;
+                m->messages += R.e_kept + N;
+                m->alg_bytes += M * (4.0 * u.HF + 4.0 + 4.0 * u.heads) + 4.0 * (Nn + 1) + 4.0 * Nn * u.in_w + 8.0 * Nn * u.HF +
+                                (gat ? 8.0 * Nn * u.heads : 0.0);
+            }
+        }
+    }
+    m->ld_x = pad4(x_cols);
+    m->alg_bytes += 4.0 * (double)N * P * d.repr_dim + 4.0 * (double)N * d.repr_dim;
+    m->pack_floats = (pack + 3) & ~(size_t)3;
+    size_t off = m->pack_floats;
+    for (Level &L : m->levels) {
+        L.off_t += off;
+        L.off_a += off;
+        L.off_o += off;
+    }
+    off += ws;
+    m->off_x = off;
+    off += (size_t)N * (size_t)m->ld_x;
+    m->off_partial = off;
+    m->partial_floats = (partial_max + 3) & ~(size_t)3;
+    off += m->partial_floats;
+    m->total_floats = off;
+    return PEA_OK;
+}
+
+int init_model(pea_model *m, const pea_plan *plan, const pea_model_desc *desc) {
+    PEA_REQUIRE(plan && desc, PEA_ERR_ARG, "model: null plan / desc");
+    PEA_REQUIRE(desc->kind == PEA_KIND_GAT || desc->kind == PEA_KIND_GCN || desc->kind == PEA_KIND_SAGE, PEA_ERR_ARG, "model: kind %d", desc->kind);
+    PEA_REQUIRE(desc->num_channels > 0 && desc->num_channels <= kMaxChannels && desc->steps && desc->relation_of, PEA_ERR_ARG,
+                "model: %d channels (1..%d)", desc->num_channels, kMaxChannels);
+    PEA_REQUIRE(desc->emb_dim > 0 && desc->hidden_size > 0 && desc->repr_dim > 0 && desc->heads > 0, PEA_ERR_ARG, "model: bad widths");
+    PEA_REQUIRE(desc->fuse_mode == PEA_FUSE_ATT || desc->fuse_mode == PEA_FUSE_MEAN, PEA_ERR_ARG,
+                "model: fuse mode %d ('concat' is unusable in the reference, models/base.py:175 vs :197)", desc->fuse_mode);
+    m->plan = plan;
+    m->d = *desc;
+    m->steps.assign(desc->steps, desc->steps + desc->num_channels);
+    int total = 0;
+    m->chan_first.clear();
+    for (int p = 0; p < desc->num_channels; ++p) {
+        PEA_REQUIRE(m->steps[(size_t)p] >= 1, PEA_ERR_ARG, "model: channel %d has %d steps", p, m->steps[(size_t)p]);
+        m->chan_first.push_back(total);
+        total += m->steps[(size_t)p];
+    }
+    m->relation_of.assign(desc->relation_of, desc->relation_of + total);
+    m->d.steps = nullptr;
+    m->d.relation_of = nullptr;
+    m->n_slots_per_layer = desc->kind == PEA_KIND_GAT ? 4 : desc->kind == PEA_KIND_GCN ? 2 : 3;
+    return build_schedule(m);
+}
+
+}  // namespace
+
+// params: [sum steps][slots] device pointers, channel-major.  ldx: row stride of x.
+// out_x / ld_out_x: when non-null the last-layer outputs go there instead of the workspace X (single-conv
+// entry points); relu_last applies relu to last layers too.
+int model_forward(pea_model *m, const float *const *params, const float *x, int64_t ldx, const float *att, int masked,
+                  float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x, int relu_last,
+                  hipStream_t stream) {
+    const pea_model_desc &d = m->d;
+    pea_plan *plan = const_cast<pea_plan *>(m->plan);
+    const int64_t N = plan->N;
+    const int kind = d.kind;
+    const int slots = m->n_slots_per_layer;
+    float *pack = wsf;
+    float *X = out_x ? out_x : wsf + m->off_x;
+    const int64_t ldX = out_x ? ld_out_x : m->ld_x;
+    float *partial = wsf + m->off_partial;
+    auto param = [&](const Unit &u, int slot) -> const float * {
+        return params[(size_t)(m->chan_first[(size_t)u.p] + u.s) * (size_t)slots + (size_t)slot];
+    };
+
+    // ---- 1. pack weights (they change every optimizer step) ----
+    std::vector<PackJob> pj;
+    for (Level &L : m->levels) {
+        for (size_t ui = 0; ui < L.units.size(); ++ui) {
+            const Unit &u = L.units[ui];
+            PackJob j{};
+            j.kind = kind;
+            j.B = pack + u.b_off;
+            j.ldb = u.ldb;
+            j.in = u.in_w;
+            j.HF = u.HF;
+            j.F = u.F;
+            j.bias = pack + u.bias_off;
+            j.w0 = param(u, 0);
+            PEA_REQUIRE(j.w0 != nullptr, PEA_ERR_ARG, "forward: null weight pointer (channel %d step %d)", u.p, u.s);
+            if (kind == PEA_KIND_GAT) {
+                j.w1 = param(u, 1);
+                j.w2 = param(u, 2);
+                j.w3 = param(u, 3);
+                PEA_REQUIRE(j.w1 && j.w2, PEA_ERR_ARG, "forward: null att_i/att_j (channel %d step %d)", u.p, u.s);
+                j.a_col = L.shared_input ? (L.n_cols + 2 * u.a_k - u.t_col) : u.HF;
+            } else if (kind == PEA_KIND_GCN) {
+                j.w3 = param(u, 1);
+            } else {
+                j.w3 = param(u, 1);
+                j.w1 = param(u, 2);
+                PEA_REQUIRE(j.w1 != nullptr, PEA_ERR_ARG, "forward: null lin_root.weight (channel %d step %d)", u.p, u.s);
+            }
+            if (L.shared_input) {  // the last unit clears the block's padding columns
+                if (ui + 1 == L.units.size()) {
+                    const int used = L.n_cols + (kind == PEA_KIND_GAT ? 2 * L.n_heads : 0);
+                    j.zero_col = used - u.t_col;
+                    j.zero_n = L.n_out - used;
+                }
+            } else {
+                const int used = u.HF + (kind == PEA_KIND_GAT ? 2 * u.heads : 0);
+                j.zero_col = used;
+                j.zero_n = u.ldb - used;
+            }
+            pj.push_back(j);
+        }
+    }
+    PEA_TRY(launch_pack(pj.data(), (int)pj.size(), stream));
+
+    // ---- 2. levels ----
+    for (size_t s = 0; s < m->levels.size(); ++s) {
+        Level &L = m->levels[s];
+        float *T = wsf + L.off_t, *A = wsf + L.off_a, *O = wsf + L.off_o;
+        const float *In = s == 0 ? x : wsf + m->levels[s - 1].off_o;
+        const int64_t ldIn = s == 0 ? ldx : m->levels[s - 1].ld_o;
+
+        auto run_groups = [&](AggMode mode) -> int {
+            std::vector<AggGroup> gs;
+            for (const GroupPlan &g : L.groups) {
+                const Relation &R = plan->rels[(size_t)g.rel];
+                AggGroup a{};
+                a.rowptr = R.rowptr;
+                a.col = R.col;
+                a.short_rows = R.short_rows;
+                a.long_items = R.long_items;
+                a.hub_rows = R.hub_rows;
+                a.hub_first = R.hub_first;
+                a.hub_count = R.hub_count;
+                a.n_short = R.n_short;
+                a.n_long = R.n_long;
+                a.n_hub = R.n_hub;
+                a.W = g.W;
+                a.F = g.F;
+                a.partial = partial + g.partial_off;
+                a.neg_slope = d.negative_slope;
+                if (mode == AGG_MEAN) {
+                    a.feat = In + g.col;
+                    a.ld_feat = (int)ldIn;
+                    a.out = T + g.out_col;
+                    a.ld_out = L.ld_t;
+                } else {
+                    a.feat = T + g.col;
+                    a.ld_feat = L.ld_t;
+                    a.a_src = A + 2 * g.a_k;
+                    a.a_dst = A + 2 * g.a_k + 1;
+                    a.ld_a = L.ld_a;
+                    a.bias = pack + g.bias_off;
+                    a.self_loop = (plan->flags & PEA_PLAN_SELF_LOOPS) ? 1 : 0;
+                    if (g.last) {
+                        a.out = X + g.out_col;
+                        a.ld_out = (int)ldX;
+                        a.relu = relu_last;
+                    } else {
+                        a.out = O + g.out_col;
+                        a.ld_out = L.ld_o;
+                        a.relu = 1;
+                    }
+                    if (mode == AGG_GCN) {
+                        PEA_TRY(ensure_dinv(plan, g.rel, d.gcn_deg_from_col != 0, stream));
+                        a.dinv = d.gcn_deg_from_col ? R.dinv_col : R.dinv_row;
+                    }
+                }
+                gs.push_back(a);
+            }
+            for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+                PEA_TRY(launch_aggregate(mode, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+            return PEA_OK;
+        };
+
+        if (kind == PEA_KIND_SAGE) {
+            PEA_TRY(run_groups(AGG_MEAN));
+            for (const Unit &u : L.units) {
+                GemmJob J{};
+                J.A1 = T + u.t_col;
+                J.lda1 = L.ld_t;
+                J.K1 = u.in_w;
+                J.A2 = In + u.in_col;
+                J.lda2 = (int)ldIn;
+                J.K2 = u.in_w;
+                J.B = pack + u.b_off;
+                J.ldb = u.ldb;
+                J.n_out = u.ldb;
+                J.bias = pack + u.bias_off;
+                J.n_seg = 1;
+                J.seg[0].c0 = 0;
+                J.seg[0].c1 = u.HF;
+                if (u.last) {
+                    J.seg[0].dst = X + u.o_col;
+                    J.seg[0].ld = (int)ldX;
+                    J.seg[0].relu = relu_last;
+                } else {
+                    J.seg[0].dst = O + u.o_col;
+                    J.seg[0].ld = L.ld_o;
+                    J.seg[0].relu = 1;
+                }
+                PEA_TRY(launch_gemm(J, nullptr, N, stream));
+            }
+        } else {
+            if (L.shared_input) {
+                GemmJob J{};
+                J.A1 = In;
+                J.lda1 = (int)ldIn;
+                J.K1 = d.emb_dim;
+                J.B = pack + L.b_off;
+                J.ldb = L.ldb;
+                J.n_out = L.n_out;
+                J.n_seg = 1;
+                J.seg[0].c0 = 0;
+                J.seg[0].c1 = L.n_cols;
+                J.seg[0].dst = T;
+                J.seg[0].ld = L.ld_t;
+                if (kind == PEA_KIND_GAT) {
+                    J.n_seg = 2;
+                    J.seg[1].c0 = L.n_cols;
+                    J.seg[1].c1 = L.n_cols + 2 * L.n_heads;
+                    J.seg[1].dst = A;
+                    J.seg[1].ld = L.ld_a;
+                }
+                PEA_TRY(launch_gemm(J, nullptr, N, stream));
+            } else {
+                for (const Unit &u : L.units) {
+                    GemmJob J{};
+                    J.A1 = In + u.in_col;
+                    J.lda1 = (int)ldIn;
+                    J.K1 = u.in_w;
+                    J.B = pack + u.b_off;
+                    J.ldb = u.ldb;
+                    J.n_out = u.ldb;
+                    J.n_seg = 1;
+                    J.seg[0].c0 = 0;
+                    J.seg[0].c1 = u.HF;
+                    J.seg[0].dst = T + u.t_col;
+                    J.seg[0].ld = L.ld_t;
+                    if (kind == PEA_KIND_GAT) {
+                        J.n_seg = 2;
+                        J.seg[1].c0 = u.HF;
+                        J.seg[1].c1 = u.HF + 2 * u.heads;
+                        J.seg[1].dst = A + 2 * u.a_k;
+                        J.seg[1].ld = L.ld_a;
+                    }
+                    PEA_TRY(launch_gemm(J, nullptr, N, stream));
+                }
+            }
+            PEA_TRY(run_groups(kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
+        }
+    }
+
+    // ---- 3. fusion ----
+    if (out_repr || out_stack)
+        PEA_TRY(launch_fuse(N, d.num_channels, d.repr_dim, X, ldX, m->x_col, att, masked, d.fuse_mode, nullptr, N, out_repr,
+                            out_stack, stream));
+    return PEA_OK;
+}
+
+}  // namespace pea
+
+// ---------------------------------------------------------------------------------------------- C ABI
+using namespace pea;
+
+extern "C" int pea_model_create(const pea_plan *plan, const pea_model_desc *desc, pea_model **out) {
+    PEA_REQUIRE(out != nullptr, PEA_ERR_ARG, "model: out is null");
+    *out = nullptr;
+    pea_model *m = new pea_model();
+    const int rc = init_model(m, plan, desc);
+    if (rc != PEA_OK) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return PEA_OK;
+}
+
+extern "C" int pea_model_destroy(pea_model *model) {
+    delete model;
+    return PEA_OK;
+}
+
+extern "C" size_t pea_model_workspace_bytes(const pea_model *model) {
+    return model ? model->total_floats * sizeof(float) + 64 : 0;
+}
+
+extern "C" int pea_model_params_per_layer(const pea_model *model) { return model ? model->n_slots_per_layer : 0; }
+
+extern "C" int pea_model_stats(const pea_model *model, int64_t *messages, double *algorithmic_bytes) {
+    PEA_REQUIRE(model, PEA_ERR_ARG, "model stats: null model");
+    if (messages) *messages = model->messages;
+    if (algorithmic_bytes) *algorithmic_bytes = model->alg_bytes;
+    return PEA_OK;
+}
+
+static float *aligned_ws(void *workspace) {
+    return reinterpret_cast<float *>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+}
+
+extern "C" int pea_model_forward(pea_model *model, const float *const *params_host, const float *x, const float *att,
+                                 int masked_channel, void *workspace, size_t workspace_bytes, float *out_repr,
+                                 float *out_stack, void *stream) {
+    PEA_REQUIRE(model && params_host && x && workspace, PEA_ERR_ARG, "forward: null argument");
+    PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(model), PEA_ERR_NOMEM, "forward: workspace %zu < %zu bytes",
+                workspace_bytes, pea_model_workspace_bytes(model));
+    PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward: masked channel %d", masked_channel);
+    PEA_REQUIRE(out_repr || out_stack, PEA_ERR_ARG, "forward: no output requested");
+    PEA_REQUIRE(model->d.fuse_mode == PEA_FUSE_MEAN || att || !out_repr, PEA_ERR_ARG, "forward: att is required for 'att' fusion");
+    return model_forward(model, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr, out_stack,
+                         nullptr, 0, 0, (hipStream_t)stream);
+}
+
+// ---- single conv layers: a one-channel, one-step schedule built on the host per call ----
+static int single_conv(int kind, const pea_plan *plan, int relation, int in_channels, int heads, int out_channels,
+                       const float *const *params, const float *x, int64_t ldx, float slope, int deg_from_col, int relu,
+                       float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream, size_t *bytes_only) {
+    pea_model m;
+    m.single_conv = true;
+    pea_model_desc d{};
+    const int steps[1] = {1};
+    const int rel[1] = {relation};
+    d.kind = kind;
+    d.num_channels = 1;
+    d.steps = steps;
+    d.relation_of = rel;
+    d.emb_dim = in_channels;
+    d.hidden_size = out_channels;
+    d.repr_dim = out_channels;
+    d.heads = heads;
+    d.fuse_mode = PEA_FUSE_MEAN;
+    d.gcn_deg_from_col = deg_from_col;
+    d.negative_slope = slope;
+    PEA_TRY(init_model(&m, plan, &d));
+    if (bytes_only) {
+        *bytes_only = m.total_floats * sizeof(float) + 64;
+        return PEA_OK;
+    }
+    PEA_REQUIRE(x && out && workspace, PEA_ERR_ARG, "conv: null argument");
+    PEA_REQUIRE(ldx >= in_channels && ldx % 4 == 0 && ldo >= (int64_t)heads * out_channels && ldo % 4 == 0, PEA_ERR_ARG,
+                "conv: row strides (%lld, %lld) must be multiples of 4 covering the row", (long long)ldx, (long long)ldo);
+    PEA_REQUIRE(workspace_bytes >= m.total_floats * sizeof(float) + 64, PEA_ERR_NOMEM, "conv: workspace too small");
+    return model_forward(&m, params, x, ldx, nullptr, -1, aligned_ws(workspace), nullptr, nullptr, out, ldo, relu,
+                         (hipStream_t)stream);
+}
+
+extern "C" int pea_gat_conv(const pea_plan *plan, int relation, int in_channels, int heads, int out_channels, const float *x,
+                            int64_t ldx, const float *lin_weight, const float *att_i, const float *att_j, const float *bias,
+                            float negative_slope, int relu, float *out, int64_t ldo, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    const float *params[4] = {lin_weight, att_i, att_j, bias};
+    return single_conv(PEA_KIND_GAT, plan, relation, in_channels, heads, out_channels, params, x, ldx, negative_slope, 0, relu,
+                       out, ldo, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int pea_gcn_conv(const pea_plan *plan, int relation, int in_channels, int out_channels, const float *x, int64_t ldx,
+                            const float *weight, const float *bias, int deg_from_col, int relu, float *out, int64_t ldo,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+    const float *params[2] = {weight, bias};
+    return single_conv(PEA_KIND_GCN, plan, relation, in_channels, 1, out_channels, params, x, ldx, 0.f, deg_from_col, relu, out,
+                       ldo, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int pea_sage_conv(const pea_plan *plan, int relation, int in_channels, int out_channels, const float *x, int64_t ldx,
+                             const float *rel_weight, const float *rel_bias, const float *root_weight, int relu, float *out,
+                             int64_t ldo, void *workspace, size_t workspace_bytes, void *stream) {
+    const float *params[3] = {rel_weight, rel_bias, root_weight};
+    return single_conv(PEA_KIND_SAGE, plan, relation, in_channels, 1, out_channels, params, x, ldx, 0.f, 0, relu, out, ldo,
+                       workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" size_t pea_conv_workspace_bytes(const pea_plan *plan, int kind, int relation, int in_channels, int heads,
+                                           int out_channels) {
+    size_t bytes = 0;
+    const int rc = single_conv(kind, plan, relation, in_channels, heads, out_channels, nullptr, nullptr, 0, 0.2f, 0, 0, nullptr,
+                               0, nullptr, 0, nullptr, &bytes);
+    return rc == PEA_OK ? bytes : 0;
+}

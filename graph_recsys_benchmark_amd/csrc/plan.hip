@@ -1,0 +1,259 @@
+// Graph plan: the one-time preprocessing of the P x S list of COO edge_index tensors the reference
+// builds in graph_recsys_benchmark/utils/general_utils.py:280-395 (int64 [2,E], row 0 = source,
+// row 1 = target, multi-edges kept) into what the gfx950 kernels consume:
+//   - destination-sorted CSR with int32 ids, STABLE (edge order inside a row = COO order), optionally
+//     with existing self loops dropped (GAT: remove_self_loops + add_self_loops, GCN:
+//     add_remaining_self_loops; the one-loop-per-node is added inside the kernels, never materialised)
+//   - degree bins: short rows (row per lane subgroup), long rows (row per wave), hub rows cut into
+//     <= 512-edge chunks (destination-degree skew)
+//   - GCN deg^-1/2 (computed once; the reference recomputes it every call)
+// The reference rebuilds the self-loop edge list and the GCN norm on every forward; here it is static.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace pea {
+namespace {
+
+__global__ void coo_to_keys(int64_t E, int64_t N, const int64_t *__restrict__ coo, int drop_loops,
+                            int *__restrict__ keys, int *__restrict__ vals, int *err) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t j = coo[e], i = coo[E + e];
+    if (j < 0 || j >= N || i < 0 || i >= N) {
+        atomicOr(err, 1);
+        keys[e] = (int)N;
+        vals[e] = 0;
+        return;
+    }
+    keys[e] = (drop_loops && i == j) ? (int)N : (int)i;  // dropped edges sort behind every real row
+    vals[e] = (int)j;
+}
+
+// rowptr[i] = first position whose key >= i  (i = 0..N)
+__global__ void rowptr_from_sorted(int64_t E, int64_t N, const int *__restrict__ keys, int *__restrict__ rowptr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < (int)i) lo = mid + 1;
+        else hi = mid;
+    }
+    rowptr[i] = (int)lo;
+}
+
+__global__ void count_sources(int64_t E, const int *__restrict__ col, int *__restrict__ cnt) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&cnt[col[e]], 1);
+}
+
+__global__ void dinv_from_counts(int64_t N, const int *__restrict__ cnt, const int *__restrict__ rowptr,
+                                 int from_col, int self_loops, float *__restrict__ dinv) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int d = (from_col ? rowptr[v + 1] - rowptr[v] : cnt[v]) + (self_loops ? 1 : 0);
+    const float r = powf((float)d, -0.5f);
+    dinv[v] = isinf(r) ? 0.f : r;
+}
+
+template <typename T>
+int upload(const std::vector<T> &h, T **d) {
+    *d = nullptr;
+    if (h.empty()) return PEA_OK;
+    PEA_HIP(hipMalloc((void **)d, h.size() * sizeof(T)));
+    PEA_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PEA_OK;
+}
+
+int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t E, hipStream_t stream) {
+    const int64_t N = plan->N;
+    const bool drop = plan->flags & PEA_PLAN_SELF_LOOPS;
+    R.e_in = E;
+    PEA_REQUIRE(E >= 0 && E < (int64_t)INT32_MAX - 64, PEA_ERR_ARG, "relation with %lld edges exceeds the int32 CSR", (long long)E);
+    PEA_HIP(hipMalloc((void **)&R.rowptr, (size_t)(N + 1) * sizeof(int)));
+    int *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *err = nullptr;
+    void *tmp = nullptr;
+    int rc = PEA_OK;
+    const size_t eb = (size_t)std::max<int64_t>(E, 1) * sizeof(int);
+    auto cleanup = [&]() {
+        (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(err); (void)hipFree(tmp);
+    };
+#define PEA_HIP_C(call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));          \
+            cleanup();                                                                                    \
+            return PEA_ERR_HIP;                                                                           \
+        }                                                                                                 \
+    } while (0)
+    PEA_HIP_C(hipMalloc((void **)&keys_in, eb));
+    PEA_HIP_C(hipMalloc((void **)&keys_out, eb));
+    PEA_HIP_C(hipMalloc((void **)&vals_in, eb));
+    PEA_HIP_C(hipMalloc((void **)&R.col, eb));
+    PEA_HIP_C(hipMalloc((void **)&err, sizeof(int)));
+    PEA_HIP_C(hipMemsetAsync(err, 0, sizeof(int), stream));
+    if (E > 0) {
+        hipLaunchKernelGGL(coo_to_keys, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, E, N, coo_dev,
+                           drop ? 1 : 0, keys_in, vals_in, err);
+        PEA_HIP_C(hipGetLastError());
+        int bits = 1;
+        while ((1ll << bits) <= N) ++bits;  // keys are in [0, N]
+        size_t tmp_bytes = 0;
+        PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
+                                            (unsigned)bits, stream));
+        PEA_HIP_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
+                                            (unsigned)bits, stream));
+    }
+    hipLaunchKernelGGL(rowptr_from_sorted, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, stream, E, N, keys_out,
+                       R.rowptr);
+    PEA_HIP_C(hipGetLastError());
+    int herr = 0;
+    PEA_HIP_C(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    std::vector<int> rp((size_t)N + 1);
+    PEA_HIP_C(hipMemcpyAsync(rp.data(), R.rowptr, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PEA_HIP_C(hipStreamSynchronize(stream));
+    cleanup();
+#undef PEA_HIP_C
+    PEA_REQUIRE(herr == 0, PEA_ERR_RANGE, "edge_index holds a node id outside [0, %lld)", (long long)N);
+    R.e_kept = rp[(size_t)N];
+
+    // ---- degree bins over the rows this rank owns (host; rowptr only) ----
+    std::vector<int> short_rows, hub_rows, hub_first, hub_count;
+    std::vector<LongItem> items;
+    const int tile = plan->shard_tile, world = plan->shard_world, rank = plan->shard_rank;
+    int max_deg = 0, slots = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int deg = rp[(size_t)i + 1] - rp[(size_t)i];
+        max_deg = std::max(max_deg, deg);
+        if (world > 1 && (int)((i / tile) % world) != rank) continue;
+        R.rows_owned++;
+        R.edges_owned += deg;
+        if (deg <= kShortDeg) {
+            short_rows.push_back((int)i);
+        } else if (deg <= kChunk) {
+            items.push_back({(int)i, rp[(size_t)i], rp[(size_t)i + 1], -1});
+        } else {
+            const int nch = (deg + kChunk - 1) / kChunk;
+            const int len = (deg + nch - 1) / nch;
+            hub_rows.push_back((int)i);
+            hub_first.push_back(slots);
+            hub_count.push_back(nch);
+            for (int c = 0; c < nch; ++c) {
+                const int b = rp[(size_t)i] + c * len;
+                const int e = std::min(b + len, rp[(size_t)i + 1]);
+                items.push_back({(int)i, b, e, slots++});
+            }
+        }
+    }
+    // longest first: the tail of the launch is made of the cheapest items
+    std::stable_sort(items.begin(), items.end(),
+                     [](const LongItem &a, const LongItem &b) { return (a.end - a.beg) > (b.end - b.beg); });
+    R.max_deg = max_deg;
+    R.n_short = (int)short_rows.size();
+    R.n_long = (int)items.size();
+    R.n_hub = (int)hub_rows.size();
+    R.n_slots = slots;
+    plan->max_slots = std::max(plan->max_slots, slots);
+    PEA_TRY(upload(short_rows, &R.short_rows));
+    PEA_TRY(upload(items, &R.long_items));
+    PEA_TRY(upload(hub_rows, &R.hub_rows));
+    PEA_TRY(upload(hub_first, &R.hub_first));
+    PEA_TRY(upload(hub_count, &R.hub_count));
+    (void)rc;
+    return PEA_OK;
+}
+
+void free_relation(Relation &R) {
+    (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col);
+    (void)hipFree(R.short_rows); (void)hipFree(R.long_items);
+    (void)hipFree(R.hub_rows); (void)hipFree(R.hub_first); (void)hipFree(R.hub_count);
+}
+
+}  // namespace
+
+int ensure_dinv(pea_plan *plan, int rel, bool from_col, hipStream_t stream) {
+    Relation &R = plan->rels[(size_t)rel];
+    float **slot = from_col ? &R.dinv_col : &R.dinv_row;
+    if (*slot) return PEA_OK;
+    const int64_t N = plan->N;
+    int *cnt = nullptr;
+    PEA_HIP(hipMalloc((void **)slot, (size_t)N * sizeof(float)));
+    PEA_HIP(hipMalloc((void **)&cnt, (size_t)N * sizeof(int)));
+    PEA_HIP(hipMemsetAsync(cnt, 0, (size_t)N * sizeof(int), stream));
+    if (!from_col && R.e_kept > 0) {
+        hipLaunchKernelGGL(count_sources, dim3((unsigned)((R.e_kept + 255) / 256)), dim3(256), 0, stream, R.e_kept,
+                           R.col, cnt);
+    }
+    hipLaunchKernelGGL(dinv_from_counts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, cnt, R.rowptr,
+                       from_col ? 1 : 0, (plan->flags & PEA_PLAN_SELF_LOOPS) ? 1 : 0, *slot);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(cnt);
+    PEA_REQUIRE(e == hipSuccess, PEA_ERR_HIP, "gcn norm: %s", hipGetErrorString(e));
+    return PEA_OK;
+}
+
+}  // namespace pea
+
+extern "C" int pea_plan_create(int64_t num_nodes, int n_relations, const int64_t *const *coo_host,
+                               const int64_t *num_edges_host, int flags, int shard_rank, int shard_world,
+                               int shard_tile, void *stream_, pea_plan **out) {
+    using namespace pea;
+    hipStream_t stream = (hipStream_t)stream_;
+    PEA_REQUIRE(out != nullptr, PEA_ERR_ARG, "plan: out is null");
+    *out = nullptr;
+    PEA_REQUIRE(num_nodes > 0 && num_nodes < (int64_t)INT32_MAX - 64, PEA_ERR_ARG, "plan: num_nodes=%lld", (long long)num_nodes);
+    PEA_REQUIRE(n_relations > 0 && coo_host && num_edges_host, PEA_ERR_ARG, "plan: no relations");
+    PEA_REQUIRE(shard_world >= 1 && shard_rank >= 0 && shard_rank < shard_world && shard_tile > 0, PEA_ERR_ARG,
+                "plan: bad shard (rank %d of %d, tile %d)", shard_rank, shard_world, shard_tile);
+    PEA_REQUIRE(pea_device_count() > 0, PEA_ERR_DEVICE, "no gfx950 device visible");
+    pea_plan *plan = new pea_plan();
+    plan->N = num_nodes;
+    plan->flags = flags;
+    plan->shard_rank = shard_rank;
+    plan->shard_world = shard_world;
+    plan->shard_tile = shard_tile;
+    plan->rels.resize((size_t)n_relations);
+    for (int r = 0; r < n_relations; ++r) {
+        int rc = PEA_ERR_ARG;
+        if (num_edges_host[r] > 0 && coo_host[r] == nullptr) set_error("plan: relation %d has a null edge_index", r);
+        else rc = build_relation(plan, plan->rels[(size_t)r], coo_host[r], num_edges_host[r], stream);
+        if (rc != PEA_OK) {
+            pea_plan_destroy(plan);
+            return rc;
+        }
+    }
+    *out = plan;
+    return PEA_OK;
+}
+
+extern "C" int pea_plan_destroy(pea_plan *plan) {
+    if (!plan) return PEA_OK;
+    for (auto &R : plan->rels) pea::free_relation(R);
+    delete plan;
+    return PEA_OK;
+}
+
+extern "C" int pea_plan_relation_info(const pea_plan *plan, int relation, int64_t *info) {
+    PEA_REQUIRE(plan && info && relation >= 0 && relation < (int)plan->rels.size(), PEA_ERR_ARG, "plan info: bad argument");
+    const pea::Relation &R = plan->rels[(size_t)relation];
+    info[0] = R.e_kept; info[1] = R.max_deg; info[2] = R.n_short; info[3] = R.n_long;
+    info[4] = R.n_hub; info[5] = R.n_slots; info[6] = R.rows_owned; info[7] = R.edges_owned;
+    return PEA_OK;
+}
+
+extern "C" int pea_plan_export_csr(const pea_plan *plan, int relation, int32_t *rowptr, int32_t *col, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PEA_REQUIRE(plan && relation >= 0 && relation < (int)plan->rels.size(), PEA_ERR_ARG, "export csr: bad argument");
+    const pea::Relation &R = plan->rels[(size_t)relation];
+    if (rowptr) PEA_HIP(hipMemcpyAsync(rowptr, R.rowptr, (size_t)(plan->N + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    if (col && R.e_kept > 0) PEA_HIP(hipMemcpyAsync(col, R.col, (size_t)R.e_kept * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    return PEA_OK;
+}

@@ -1,0 +1,249 @@
+"""Host side of the HIP path: graph plan + whole-model schedule behind the reference's module surface.
+
+    GraphPlan  <-  the P x S list of int64 COO tensors built by update_pea_graph_input
+                   (reference graph_recsys_benchmark/utils/general_utils.py:280-395)
+    PEAEngine  <-  PEABaseRecsysModel.forward (reference models/base.py:191-206) for one conv kind
+
+PyTorch is used for device memory and streams only; all arithmetic runs in libpeahip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+KINDS = {'gat': _lib.KIND_GAT, 'gcn': _lib.KIND_GCN, 'sage': _lib.KIND_SAGE}
+# parameter slots per conv layer, in the order pea_model_forward expects (include/peahip.h)
+PARAM_SLOTS = {
+    'gat': ('lin.weight', 'att_i', 'att_j', 'bias'),
+    'gcn': ('weight', 'bias'),
+    'sage': ('lin_rel.weight', 'lin_rel.bias', 'lin_root.weight'),
+}
+
+
+def _fingerprint(ei):
+    e = ei.shape[1]
+    if e == 0:
+        return (0, 0)
+    idx = torch.arange(e, device=ei.device, dtype=torch.int64)
+    h = (ei[0] * 1000003 + ei[1] * 998244353 + idx * 7919).sum()
+    return (e, int(h.item()))
+
+
+class GraphPlan:
+    """Destination-sorted CSR + degree bins for every DISTINCT relation of a metapath list.
+
+    Equal-content tensors are planned once: update_pea_graph_input creates a fresh
+    torch.flip(user2item) copy per use (utils/general_utils.py:300-307), so dedupe is by content.
+    """
+
+    def __init__(self, num_nodes, meta_path_edge_index_list, self_loops, shard_rank=0, shard_world=1,
+                 shard_tile=256):
+        lib = _lib.require_device()
+        self.num_nodes = int(num_nodes)
+        self.self_loops = bool(self_loops)
+        self.shard = (int(shard_rank), int(shard_world), int(shard_tile))
+        uniq, keys = [], {}
+        self.relation_of = []
+        for eil in meta_path_edge_index_list:
+            row = []
+            for ei in eil:
+                if ei.dim() != 2 or ei.shape[0] != 2 or ei.dtype != torch.int64:
+                    raise ValueError('edge_index must be an int64 [2, E] tensor, got %s %s' % (ei.dtype, tuple(ei.shape)))
+                if not ei.is_cuda:
+                    raise RuntimeError('edge_index must live on the GPU (the HIP path has no CPU fallback)')
+                ei = ei.contiguous()
+                fp = _fingerprint(ei)
+                found = None
+                for cand in keys.get(fp, []):
+                    if torch.equal(uniq[cand], ei):
+                        found = cand
+                        break
+                if found is None:
+                    found = len(uniq)
+                    uniq.append(ei)
+                    keys.setdefault(fp, []).append(found)
+                row.append(found)
+            self.relation_of.append(row)
+        self.num_relations = len(uniq)
+        ptrs = (C.c_void_p * len(uniq))(*[t.data_ptr() for t in uniq])
+        nedge = (C.c_int64 * len(uniq))(*[t.shape[1] for t in uniq])
+        handle = C.c_void_p()
+        _lib.check(lib.pea_plan_create(self.num_nodes, len(uniq), ptrs, nedge,
+                                       _lib.PLAN_SELF_LOOPS if self_loops else 0, self.shard[0], self.shard[1],
+                                       self.shard[2], _lib.current_stream(), C.byref(handle)))
+        self._h = handle
+        self.device = uniq[0].device
+
+    def relation_info(self, r):
+        info = (C.c_int64 * 8)()
+        _lib.check(_lib.load().pea_plan_relation_info(self._h, r, info))
+        names = ('edges', 'max_degree', 'short_rows', 'long_items', 'hub_rows', 'hub_chunks', 'rows_owned', 'edges_owned')
+        return dict(zip(names, [int(v) for v in info]))
+
+    def export_csr(self, r):
+        info = self.relation_info(r)
+        rowptr = torch.empty(self.num_nodes + 1, dtype=torch.int32, device=self.device)
+        col = torch.empty(max(info['edges'], 1), dtype=torch.int32, device=self.device)
+        _lib.check(_lib.load().pea_plan_export_csr(self._h, r, _lib.ptr(rowptr), _lib.ptr(col), _lib.current_stream()))
+        return rowptr, col[:info['edges']]
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.load().pea_plan_destroy(h)
+            except Exception:
+                pass
+
+
+class PEAEngine:
+    """One scheduled PEA forward: P channels x S conv layers of one kind, then fusion."""
+
+    def __init__(self, plan, kind, steps, emb_dim, hidden_size, repr_dim, heads=1, channel_aggr='att',
+                 gcn_deg_from='row', negative_slope=0.2):
+        if channel_aggr not in ('att', 'mean'):
+            # 'concat' cannot work in the reference either (models/base.py:175 sizes fc1 for 'cat')
+            raise NotImplementedError('Other aggr methods not implemeted!')
+        if kind not in KINDS:
+            raise ValueError(kind)
+        if gcn_deg_from not in ('row', 'col'):
+            raise ValueError(gcn_deg_from)
+        lib = _lib.require_device()
+        self.plan, self.kind = plan, kind
+        self.steps = [int(s) for s in steps]
+        if len(self.steps) != len(plan.relation_of) or any(len(r) != s for r, s in zip(plan.relation_of, self.steps)):
+            raise AssertionError('meta_path_steps does not match the edge index lists')
+        self.P = len(self.steps)
+        self.repr_dim, self.emb_dim = int(repr_dim), int(emb_dim)
+        self.channel_aggr = channel_aggr
+        flat = [r for row in plan.relation_of for r in row]
+        self._steps_c = (C.c_int * self.P)(*self.steps)
+        self._rel_c = (C.c_int * len(flat))(*flat)
+        desc = _lib.ModelDesc(KINDS[kind], self.P, self._steps_c, self._rel_c, int(emb_dim), int(hidden_size),
+                              int(repr_dim), int(heads), _lib.FUSE_ATT if channel_aggr == 'att' else _lib.FUSE_MEAN,
+                              1 if gcn_deg_from == 'col' else 0, float(negative_slope))
+        handle = C.c_void_p()
+        _lib.check(lib.pea_model_create(plan._h, C.byref(desc), C.byref(handle)))
+        self._h = handle
+        self.workspace_bytes = int(lib.pea_model_workspace_bytes(handle))
+        self._ws = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=plan.device)
+        self.n_layers = sum(self.steps)
+        self.slots = len(PARAM_SLOTS[kind])
+        msgs, ab = C.c_int64(), C.c_double()
+        _lib.check(lib.pea_model_stats(handle, C.byref(msgs), C.byref(ab)))
+        self.messages, self.algorithmic_bytes = int(msgs.value), float(ab.value)
+
+    def forward(self, layer_params, x, att=None, masked=None, want_stack=False):
+        """layer_params: list (channel-major, then step) of tuples of tensors in PARAM_SLOTS order
+        (a missing bias may be None)."""
+        lib = _lib.load()
+        n = self.plan.num_nodes
+        if x.shape != (n, self.emb_dim) or x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError('x must be a CUDA float32 [%d, %d] tensor' % (n, self.emb_dim))
+        if len(layer_params) != self.n_layers:
+            raise ValueError('expected %d conv layers, got %d' % (self.n_layers, len(layer_params)))
+        keep = [x.contiguous()]
+        ptrs = (C.c_void_p * (self.n_layers * self.slots))()
+        k = 0
+        for lp in layer_params:
+            if len(lp) != self.slots:
+                raise ValueError('each %s layer needs %d parameter tensors' % (self.kind, self.slots))
+            for t in lp:
+                if t is None:
+                    ptrs[k] = None
+                else:
+                    t = t.detach()
+                    if t.dtype != torch.float32 or not t.is_cuda:
+                        raise ValueError('parameters must be CUDA float32 tensors')
+                    t = t.contiguous()
+                    keep.append(t)
+                    ptrs[k] = t.data_ptr()
+                k += 1
+        att_t = None
+        if self.channel_aggr == 'att':
+            if att is None:
+                raise ValueError("att is required for channel_aggr='att'")
+            att_t = att.detach().reshape(self.P, self.repr_dim).contiguous()
+            keep.append(att_t)
+        out = torch.empty((n, self.repr_dim), dtype=torch.float32, device=x.device)
+        stack = torch.empty((n, self.P, self.repr_dim), dtype=torch.float32, device=x.device) if want_stack else None
+        _lib.check(lib.pea_model_forward(self._h, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t),
+                                         -1 if masked is None else int(masked), _lib.ptr(self._ws),
+                                         self.workspace_bytes, _lib.ptr(out), _lib.ptr(stack), _lib.current_stream()))
+        return (out, stack) if want_stack else out
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.load().pea_model_destroy(h)
+            except Exception:
+                pass
+
+
+def bpr_score(repr_, triples, fc1_w, fc1_b, fc2_w, fc2_b, want_preds=False, validate=False):
+    """loss = -sum(log(sigmoid(pos - neg))) over rows (u, i+, i-) of `triples` (reference models/base.py:46-48,
+    208-214).  Returns a 0-dim tensor (and pos, neg [B] when asked)."""
+    lib = _lib.require_device()
+    if triples.dtype != torch.int64 or triples.dim() != 2 or triples.shape[1] < 3:
+        raise ValueError('triples must be int64 [B, >=3]')
+    if triples.stride(1) != 1:
+        triples = triples.contiguous()
+    b = triples.shape[0]
+    r = repr_.shape[1]
+    dev = repr_.device
+    ws_bytes = int(lib.pea_bpr_workspace_bytes(b))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    pos = torch.empty(b, dtype=torch.float32, device=dev) if want_preds else None
+    neg = torch.empty(b, dtype=torch.float32, device=dev) if want_preds else None
+    args = [t.detach().contiguous() for t in (repr_, fc1_w, fc1_b, fc2_w, fc2_b)]
+    _lib.check(lib.pea_bpr_score(b, r, repr_.shape[0], _lib.ptr(args[0]), _lib.ptr(triples), triples.stride(0),
+                                 _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(args[3]), _lib.ptr(args[4]),
+                                 _lib.ptr(pos), _lib.ptr(neg), _lib.ptr(loss), _lib.ptr(ws), ws_bytes,
+                                 _lib.current_stream()))
+    if validate and int(ws[:4].view(torch.int32).item()) != 0:
+        raise IndexError('index out of range in BPR triples')
+    return (loss, pos, neg) if want_preds else loss
+
+
+def predict(repr_, unids, inids, fc1_w, fc1_b, fc2_w, fc2_b):
+    """fc2(relu(fc1([repr[u] || repr[i]]))) -> [B, 1]  (reference models/base.py:208-214)."""
+    lib = _lib.require_device()
+    unids = unids.to(torch.int64).contiguous()
+    inids = inids.to(torch.int64).contiguous()
+    if unids.shape != inids.shape or unids.dim() != 1:
+        raise ValueError('unids / inids must be 1-d of equal length')
+    b = unids.shape[0]
+    out = torch.empty(b, dtype=torch.float32, device=repr_.device)
+    args = [t.detach().contiguous() for t in (repr_, fc1_w, fc1_b, fc2_w, fc2_b)]
+    rc = lib.pea_predict(b, repr_.shape[1], repr_.shape[0], _lib.ptr(args[0]), _lib.ptr(unids), _lib.ptr(inids),
+                         _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(args[3]), _lib.ptr(args[4]), _lib.ptr(out),
+                         _lib.current_stream())
+    if rc == -2:
+        raise IndexError(_lib.last_error())
+    _lib.check(rc)
+    return out.view(-1, 1)
+
+
+def rank_eval(repr_, unids, cand, fc1_w, fc1_b, fc2_w, fc2_b):
+    """Batched evaluator (reference solvers.py:56-96): cand [U, C], column 0 = the held-out positive.
+    Returns scores [U, C], rank of the positive [U] (int32), auc [U], eval loss [U]."""
+    lib = _lib.require_device()
+    unids = unids.to(torch.int64).contiguous()
+    cand = cand.to(torch.int64).contiguous()
+    u, c = cand.shape
+    dev = repr_.device
+    scores = torch.empty((u, c), dtype=torch.float32, device=dev)
+    rank = torch.empty(u, dtype=torch.int32, device=dev)
+    auc = torch.empty(u, dtype=torch.float32, device=dev)
+    loss = torch.empty(u, dtype=torch.float32, device=dev)
+    args = [t.detach().contiguous() for t in (repr_, fc1_w, fc1_b, fc2_w, fc2_b)]
+    rc = lib.pea_rank_eval(u, c, repr_.shape[1], repr_.shape[0], _lib.ptr(args[0]), _lib.ptr(unids), _lib.ptr(cand),
+                           _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(args[3]), _lib.ptr(args[4]),
+                           _lib.ptr(scores), _lib.ptr(rank), _lib.ptr(auc), _lib.ptr(loss), _lib.current_stream())
+    if rc == -2:
+        raise IndexError(_lib.last_error())
+    _lib.check(rc)
+    return scores, rank, auc, loss

@@ -1,0 +1,169 @@
+"""Host mirror of the reference's PEA model surface, with the arithmetic routed to the gfx950 HIP library.
+
+Mirrors (names, kwargs, attributes, error behaviour) graph_recsys_benchmark/models/base.py:
+    GraphRecsysModel      :29-96   loss() / eval() contract (BPR term :43-48, eval cache :88-96)
+    PEABaseChannel        :129-140 relu between steps, none after the last
+    PEABaseRecsysModel    :143-214 kwargs read at :148-152,156,167-179; forward / predict
+Differences, all on purpose:
+  * forward() hands ALL channels and steps to one schedule (engine.PEAEngine) instead of looping in Python;
+  * graph tensors must be on the GPU; there is no CPU fallback (parity checks use oracle/ from the tests);
+  * forward-only so far: loss() in training mode with autograd enabled raises (backward = SURVEY 8f rank 1).
+"""
+import torch
+from torch.nn import Parameter
+
+from .. import engine as _engine
+from ..nn.inits import glorot
+
+
+class GraphRecsysModel(torch.nn.Module):
+    def __init__(self, **kwargs):
+        super().__init__()
+        self._init(**kwargs)
+        self.reset_parameters()
+
+    def _init(self, **kwargs):
+        raise NotImplementedError
+
+    def reset_parameters(self):
+        raise NotImplementedError
+
+    def update_graph_input(self, dataset):
+        raise NotImplementedError
+
+    def predict(self, unids, inids):
+        raise NotImplementedError
+
+    def loss(self, pos_neg_pair_t):
+        """-sum(log(sigmoid(pos - neg))) over rows (u, i+, i-[, entity columns]); in training mode the full-graph
+        forward is recomputed first, exactly like the reference (models/base.py:44-45)."""
+        if self.training:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError(
+                    'the HIP path is forward-only so far (backward is SURVEY.md section 8f rank 1); '
+                    'run training-mode loss() under torch.no_grad()')
+            self.cached_repr = self.forward()
+        cf_loss = _engine.bpr_score(self.cached_repr, pos_neg_pair_t, self.fc1.weight, self.fc1.bias,
+                                    self.fc2.weight, self.fc2.bias)
+        if self.entity_aware and self.training:
+            # entity-aware regulariser (models/base.py:50-76): squared L2 distances between raw x rows
+            t = pos_neg_pair_t
+            x = self.x.detach()
+
+            def sqdist(a, b):
+                d = x[t[:, a]] - x[t[:, b]]
+                return (d * d).sum(dim=-1)
+
+            item_term = (sqdist(1, 3) - sqdist(1, 4)) * t[:, 5]
+            user_term = (sqdist(0, 6) - sqdist(0, 7)) * t[:, 8]
+            reg = -item_term.sigmoid().log().sum() - user_term.sigmoid().log().sum()
+            return cf_loss + self.entity_aware_coff * reg
+        return cf_loss
+
+    def eval(self, metapath_idx=None):
+        """nn.Module.eval() + refresh of the cached full-graph representation.  Like the reference
+        (models/base.py:88-96) the ablation index is honoured only by classes whose NAME starts with 'PEA'."""
+        super().eval()
+        with torch.no_grad():
+            if self.__class__.__name__[:3] == 'PEA':
+                self.cached_repr = self.forward(metapath_idx)
+            else:
+                self.cached_repr = self.forward()
+        return self
+
+
+class PEABaseChannel(torch.nn.Module):
+    def reset_parameters(self):
+        for module in self.gnn_layers:
+            module.reset_parameters()
+
+    def forward(self, x, edge_index_list):
+        assert len(edge_index_list) == self.num_steps
+        for step_idx in range(self.num_steps - 1):
+            x = self.gnn_layers[step_idx](x, edge_index_list[step_idx], relu=True)   # conv + F.relu fused
+        return self.gnn_layers[-1](x, edge_index_list[-1])
+
+
+class PEABaseRecsysModel(GraphRecsysModel):
+    kind = None   # 'gat' | 'gcn' | 'sage', set by the concrete model
+
+    def _init(self, **kwargs):
+        self.entity_aware = kwargs['entity_aware']
+        self.entity_aware_coff = kwargs['entity_aware_coff']
+        self.meta_path_steps = kwargs['meta_path_steps']
+        self.if_use_features = kwargs['if_use_features']
+        self.channel_aggr = kwargs['channel_aggr']
+        self.gcn_deg_from = kwargs.get('gcn_deg_from', 'row')
+
+        if not self.if_use_features:
+            self.x = Parameter(torch.Tensor(kwargs['dataset']['num_nodes'], kwargs['emb_dim']))
+        else:
+            raise NotImplementedError('Feature not implemented!')
+
+        meta_path_edge_index_list = self.update_graph_input(kwargs['dataset'])
+        assert len(meta_path_edge_index_list) == len(kwargs['meta_path_steps'])
+        self.meta_path_edge_index_list = meta_path_edge_index_list   # plain attribute, like the reference
+
+        self.pea_channels = torch.nn.ModuleList()
+        for num_steps in kwargs['meta_path_steps']:
+            kwargs_cpy = kwargs.copy()
+            kwargs_cpy['num_steps'] = num_steps
+            self.pea_channels.append(kwargs_cpy['channel_class'](**kwargs_cpy))
+
+        num_paths = len(kwargs['meta_path_steps'])
+        if self.channel_aggr == 'att':
+            self.att = Parameter(torch.Tensor(1, num_paths, kwargs['repr_dim']))
+        if self.channel_aggr == 'cat':
+            self.fc1 = torch.nn.Linear(2 * num_paths * kwargs['repr_dim'], kwargs['repr_dim'])
+        else:
+            self.fc1 = torch.nn.Linear(2 * kwargs['repr_dim'], kwargs['repr_dim'])
+        self.fc2 = torch.nn.Linear(kwargs['repr_dim'], 1)
+        self._dims = (kwargs['emb_dim'], kwargs['hidden_size'], kwargs['repr_dim'], kwargs.get('num_heads', 1))
+        self._engine = None
+
+    def reset_parameters(self):
+        if not self.if_use_features:
+            glorot(self.x)
+        for module in self.pea_channels:
+            module.reset_parameters()
+        glorot(self.fc1.weight)
+        glorot(self.fc2.weight)
+        if self.channel_aggr == 'att':
+            glorot(self.att)
+
+    # ------------------------------------------------------------------ HIP schedule
+    def _get_engine(self):
+        if self._engine is None:
+            if self.channel_aggr not in ('att', 'mean'):
+                raise NotImplementedError('Other aggr methods not implemeted!')
+            emb, hidden, repr_dim, heads = self._dims
+            plan = _engine.GraphPlan(self.x.shape[0], self.meta_path_edge_index_list,
+                                     self_loops=self.kind in ('gat', 'gcn'))
+            self._engine = _engine.PEAEngine(plan, self.kind, self.meta_path_steps, emb, hidden, repr_dim,
+                                             heads=heads if self.kind == 'gat' else 1,
+                                             channel_aggr=self.channel_aggr, gcn_deg_from=self.gcn_deg_from)
+        return self._engine
+
+    def _layer_params(self):
+        slots = _engine.PARAM_SLOTS[self.kind]
+        out = []
+        for channel in self.pea_channels:
+            for layer in channel.gnn_layers:
+                sd = dict(layer.named_parameters())
+                out.append(tuple(sd.get(name) for name in slots))
+        return out
+
+    def forward(self, metapath_idx=None, return_stack=False):
+        if not self.x.is_cuda:
+            raise RuntimeError('the HIP path needs the model on a GPU (there is no CPU fallback)')
+        for channel in self.pea_channels:
+            for layer in channel.gnn_layers:
+                if self.training and getattr(layer, 'dropout', 0) > 0:
+                    raise NotImplementedError('attention dropout > 0 is not implemented (p = 0 in every reference script)')
+        eng = self._get_engine()
+        return eng.forward(self._layer_params(), self.x.detach(), getattr(self, 'att', None), masked=metapath_idx,
+                           want_stack=return_stack)
+
+    def predict(self, unids, inids):
+        return _engine.predict(self.cached_repr, unids, inids, self.fc1.weight, self.fc1.bias, self.fc2.weight,
+                               self.fc2.bias)

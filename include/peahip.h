@@ -1,0 +1,190 @@
+/*
+ * peahip -- C-ABI of the MI355X (gfx950) metapath-GNN aggregation path.
+ *
+ * The reference (ecml-peagnn/graph_recsys_benchmark) has no FFI of its own: its hot path is a
+ * Python class surface that bottoms out in torch-geometric 1.5.0 / torch-scatter 2.0.5 ops.  This
+ * header is what a maintainer binds (ctypes) to replace, for that path only:
+ *
+ *   pea_plan_*          graph_recsys_benchmark/utils/general_utils.py:280-395 (update_pea_graph_input:
+ *                       the P x S list of int64 COO [2,E] tensors is the wire format handed over here)
+ *   pea_gat_conv        torch_geometric.nn.GATConv.forward   -- ctor sites models/peagat.py:16-21,
+ *   pea_gcn_conv        torch_geometric.nn.GCNConv.forward      models/peagcn.py:16-21,
+ *   pea_sage_conv       torch_geometric.nn.SAGEConv.forward     models/peasage.py:16-21; call site
+ *                                                               models/base.py:138-139
+ *   pea_fuse            models/base.py:193-203   (channel stack, ablation mask, 'att' / 'mean' fusion)
+ *   pea_bpr_score       models/base.py:208-214 (predict) + models/base.py:46-48 (BPR loss)
+ *   pea_model_*         models/base.py:129-140 + 191-206 (PEABaseChannel.forward loop x P channels,
+ *                       then fusion) as ONE scheduled sequence of launches on one stream
+ *   pea_rank_eval       solvers.py:85-96 (predict 1+99 candidates, sort, hit vector -> rank of the
+ *                       positive; HR/NDCG/AUC follow utils/rec_utils.py:7-30)
+ *
+ * Conventions
+ *   - extern "C"; every function returns int: 0 = ok, < 0 = error (pea_last_error() gives a
+ *     thread-local message).  No exceptions, no C++ or torch types cross the boundary.
+ *   - All array arguments are DEVICE pointers unless the name ends in _host.  The caller owns every
+ *     buffer; the library allocates only the opaque handles' internals.
+ *   - `stream` is a hipStream_t passed as void* (0 = null stream).  Every launch goes on it; no
+ *     function synchronises the device except pea_plan_create (one-time graph preprocessing).
+ *   - fp32 features, int64 ids at the surface (values < num_nodes < 2^31; the plan narrows to int32).
+ *   - Handles are immutable after creation and may be used from one stream at a time.
+ */
+#ifndef PEAHIP_H_
+#define PEAHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEA_OK 0
+#define PEA_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported width)          */
+#define PEA_ERR_RANGE (-2)    /* an edge_index / id value outside [0, num_nodes)                */
+#define PEA_ERR_HIP (-3)      /* a HIP runtime call failed                                      */
+#define PEA_ERR_NOMEM (-4)    /* workspace too small / allocation failed                        */
+#define PEA_ERR_DEVICE (-5)   /* no gfx950 device / kernel image missing                        */
+
+/* conv kinds */
+#define PEA_KIND_GAT 0
+#define PEA_KIND_GCN 1
+#define PEA_KIND_SAGE 2
+
+/* plan flags */
+#define PEA_PLAN_SELF_LOOPS 1 /* drop existing self loops, add one per node (GAT: remove_self_loops +
+                                 add_self_loops; GCN: add_remaining_self_loops with unit weights).
+                                 Leave clear for SAGE, which aggregates the edge list as given.   */
+
+/* fusion modes (models/base.py:197-203; 'concat' is unusable in the reference, not offered) */
+#define PEA_FUSE_ATT 0
+#define PEA_FUSE_MEAN 1
+
+typedef struct pea_plan pea_plan;
+typedef struct pea_model pea_model;
+
+const char *pea_version(void);
+const char *pea_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => compute entry points return PEA_ERR_DEVICE) */
+int pea_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph plan: destination-sorted CSR (multi-edges kept, edge order preserved inside a row), degree
+ * bins and hub-row chunking for every DISTINCT relation of a model.  One-time; synchronises.
+ *
+ * coo_host[r] : DEVICE pointer to relation r's int64 [2, num_edges[r]] row-major COO
+ *               (row 0 = source j, row 1 = target i: PyG flow source_to_target); the array of
+ *               pointers itself lives on the host.
+ * shard_*     : destination-row ownership for multi-GPU runs: row i belongs to rank
+ *               (i / shard_tile) % shard_world.  world = 1 -> every row.
+ * ---------------------------------------------------------------------------------------------- */
+int pea_plan_create(int64_t num_nodes, int n_relations, const int64_t *const *coo_host,
+                    const int64_t *num_edges_host, int flags, int shard_rank, int shard_world,
+                    int shard_tile, void *stream, pea_plan **out);
+int pea_plan_destroy(pea_plan *plan);
+/* info_host[0..7] = {edges kept, max in-degree, #short rows, #long items, #hub rows, #hub chunks,
+ *                    rows owned, edges owned} for one relation */
+int pea_plan_relation_info(const pea_plan *plan, int relation, int64_t *info_host);
+/* copies the CSR of one relation back (tests): rowptr int32 [N+1], col int32 [edges kept] (device) */
+int pea_plan_export_csr(const pea_plan *plan, int relation, int32_t *rowptr, int32_t *col, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-model schedule.  P channels; channel p runs steps[p] conv layers over relations
+ * relation_of[p][s] (indices into the plan), all of one `kind`, widths emb_dim -> hidden*heads ->
+ * ... -> repr_dim exactly as PEA{GAT,GCN,Sage}Channel builds them (models/peagat.py:14-21):
+ * every layer but the last of a multi-step channel has `heads` heads (GAT), the last has 1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pea_model_desc {
+    int kind;               /* PEA_KIND_*                                                     */
+    int num_channels;       /* P                                                              */
+    const int *steps;       /* [P] host                                                       */
+    const int *relation_of; /* [sum steps] host, channel-major                                */
+    int emb_dim, hidden_size, repr_dim, heads;
+    int fuse_mode;          /* PEA_FUSE_*                                                     */
+    int gcn_deg_from_col;   /* 0 = degree over the source index (PyG <= 1.5.0), 1 = target    */
+    float negative_slope;   /* GAT leaky_relu slope (0.2)                                     */
+} pea_model_desc;
+
+int pea_model_create(const pea_plan *plan, const pea_model_desc *desc, pea_model **out);
+int pea_model_destroy(pea_model *model);
+size_t pea_model_workspace_bytes(const pea_model *model);
+/* number of float* parameter slots per conv layer for this kind:
+ *   GAT : lin.weight [H*F, in], att_i [H*F], att_j [H*F], bias [H*F]          -> 4
+ *   GCN : weight [in, F], bias [F]                                            -> 2
+ *   SAGE: lin_rel.weight [F, in], lin_rel.bias [F], lin_root.weight [F, in]   -> 3              */
+int pea_model_params_per_layer(const pea_model *model);
+
+/* params_host: host array of DEVICE pointers, channel-major then layer-major then slot (see above).
+ * x [N, emb_dim]; att [P, repr_dim] (ignored for PEA_FUSE_MEAN); masked_channel = -1 or the channel
+ * zeroed before fusion (models/base.py:194-195).
+ * out_repr [N, repr_dim]; out_stack: optional [N, P, repr_dim] (channel order, torch.cat layout), may
+ * be NULL.  Only rows owned by this rank's shard are written (all rows when shard_world = 1).      */
+int pea_model_forward(pea_model *model, const float *const *params_host, const float *x,
+                      const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
+                      float *out_repr, float *out_stack, void *stream);
+/* messages reduced by one forward (sum over channels/steps of kept edges + self loops), and the
+ * algorithmic HBM bytes of SURVEY.md section 8(d) for this model -- the roofline yardstick. */
+int pea_model_stats(const pea_model *model, int64_t *messages, double *algorithmic_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single conv layers (the drop-in GATConv/GCNConv/SAGEConv modules call these).
+ * x [N, in] with row stride ldx (floats); out [N, heads*out_channels] with row stride ldo.
+ * workspace: pea_conv_workspace_bytes(...) bytes (0 = bad arguments, see pea_last_error()).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pea_conv_workspace_bytes(const pea_plan *plan, int kind, int relation, int in_channels, int heads,
+                                int out_channels);
+int pea_gat_conv(const pea_plan *plan, int relation, int in_channels, int heads, int out_channels,
+                 const float *x, int64_t ldx, const float *lin_weight, const float *att_i,
+                 const float *att_j, const float *bias, float negative_slope, int relu, float *out,
+                 int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+int pea_gcn_conv(const pea_plan *plan, int relation, int in_channels, int out_channels, const float *x,
+                 int64_t ldx, const float *weight, const float *bias, int deg_from_col, int relu,
+                 float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+int pea_sage_conv(const pea_plan *plan, int relation, int in_channels, int out_channels, const float *x,
+                  int64_t ldx, const float *rel_weight, const float *rel_bias, const float *root_weight,
+                  int relu, float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fusion of the channel stack (models/base.py:196-203).
+ * stack: channel p's [N, R] block starts at column col_of_channel_host[p] of a row-major
+ * [N, ld_stack] matrix (torch.cat layout: col = p*R, ld = P*R).  att [P, R] or NULL for MEAN.
+ * ---------------------------------------------------------------------------------------------- */
+int pea_fuse(int64_t num_nodes, int P, int R, const float *stack, int64_t ld_stack,
+             const int *col_of_channel_host, const float *att, int masked_channel, int fuse_mode,
+             float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BPR scoring (models/base.py:208-214, 46-48): for each of B rows (u, i+, i-) of `triples`
+ * (int64, row stride triple_stride >= 3 -- 9 for entity-aware batches):
+ *   pos = fc2(relu(fc1([repr[u] || repr[i+]])));  neg likewise;  loss = -sum(log(sigmoid(pos - neg)))
+ * fc1_w [R, 2R], fc1_b [R], fc2_w [1, R], fc2_b [1].  pos/neg [B] (may be NULL), loss [1].
+ * workspace: pea_bpr_workspace_bytes(B) bytes.  Deterministic (no float atomics).  Stays asynchronous: a row
+ * with an id outside [0, num_nodes) contributes nothing and sets the int at workspace[0] to 1 (the host
+ * mirror checks it when asked to validate).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pea_bpr_workspace_bytes(int64_t B);
+int pea_bpr_score(int64_t B, int R, int64_t num_nodes, const float *repr, const int64_t *triples,
+                  int64_t triple_stride, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                  const float *fc2_b, float *pos, float *neg, float *loss, void *workspace,
+                  size_t workspace_bytes, void *stream);
+/* predict only (models/base.py:208-214): pred[b] for pairs (unids[b], inids[b]).  pea_predict and
+ * pea_rank_eval synchronise the stream once to report ids outside [0, num_nodes) as PEA_ERR_RANGE. */
+int pea_predict(int64_t B, int R, int64_t num_nodes, const float *repr, const int64_t *unids,
+                const int64_t *inids, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                const float *fc2_b, float *pred, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched evaluator (solvers.py:56-96 per-user loop as one launch): U users, C candidates each
+ * (candidate 0 is the held-out positive, 1..C-1 the sampled negatives, ids drawn on the host with
+ * np.random.choice for bit-exactness).  Writes per user: scores [U, C], rank of the positive
+ * (number of negatives scoring strictly higher + ties placed as torch.sort(descending, stable)
+ * would: a tie with an earlier index wins), auc [U], eval loss [U] (= -sum log sigmoid(pos - neg)).
+ * ---------------------------------------------------------------------------------------------- */
+int pea_rank_eval(int64_t U, int C, int R, int64_t num_nodes, const float *repr, const int64_t *unids,
+                  const int64_t *cand /*[U, C]*/, const float *fc1_w, const float *fc1_b,
+                  const float *fc2_w, const float *fc2_b, float *scores, int32_t *rank, float *auc,
+                  float *loss, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEAHIP_H_ */
