@@ -55,6 +55,8 @@ SIGNATURES = {
     'pea_bpr_workspace_bytes': (_sz, [_i64]),
     'pea_bpr_score': (_int, [_i64, _int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pea_predict': (_int, [_i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pea_profile_enable': (_int, [_int]),
+    'pea_profile_read': (_int, [_int, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(_int)]),
     'pea_rank_eval': (_int, [_i64, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -300,9 +300,32 @@ int lanes_for(int W) {
     return g;
 }
 
+// kernel names as rocprofv3 would group them: agg_{short,long,merge}_g<G>_{gat,gcn,mean}
+template <int G, int MODE>
+const char *kname(int which) {
+    static char names[3][32];
+    static bool init = false;
+    if (!init) {
+        const char *w[3] = {"short", "long", "merge"};
+        const char *m = MODE == AGG_GAT ? "gat" : MODE == AGG_GCN ? "gcn" : "mean";
+        for (int i = 0; i < 3; ++i) snprintf(names[i], sizeof(names[i]), "agg_%s_g%d_%s", w[i], G, m);
+        init = true;
+    }
+    return names[which];
+}
+
 template <int G, int MODE>
 int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
     AggLaunch L;
+    // algorithmic bytes of SURVEY.md 8(d) attributed to a launch: per message 4 B per gathered feature column
+    // + 4 B source index + 4 B per attention scalar (GAT) / norm scalar (GCN), times the messages it reduces
+    double bytes_short = 0.0, bytes_long = 0.0;
+    for (int i = 0; i < n_sel; ++i) {
+        const AggGroup &g = base.g[sel[i]];
+        const double per_msg = 4.0 * g.W + 4.0 * g.idx_share + (MODE == AGG_GAT ? 4.0 * (g.W / g.F) : MODE == AGG_GCN ? 4.0 * g.idx_share : 0.0);
+        bytes_short += per_msg * g.msgs_short;
+        bytes_long += per_msg * g.msgs_long;
+    }
     // short
     L.n_groups = 0;
     int blocks = 0;
@@ -315,6 +338,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     }
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
+        ProfScope ps(kname<G, MODE>(0), stream, bytes_short);
         hipLaunchKernelGGL((agg_short_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
@@ -330,6 +354,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     }
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
+        ProfScope ps(kname<G, MODE>(1), stream, bytes_long);
         hipLaunchKernelGGL((agg_long_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
@@ -345,6 +370,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     }
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
+        ProfScope ps(kname<G, MODE>(2), stream, 0.0);
         hipLaunchKernelGGL((agg_merge_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }

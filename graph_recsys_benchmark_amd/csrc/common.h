@@ -39,6 +39,17 @@ const char *get_error();
         if (rc_ != PEA_OK) return rc_;                                                         \
     } while (0)
 
+// per-launch HIP-event timing (prof.hip); a no-op unless pea_profile_enable(1) was called
+bool prof_enabled();
+class ProfScope {
+  public:
+    ProfScope(const char *name, hipStream_t stream, double units = 0.0);
+    ~ProfScope();
+  private:
+    int idx_;
+    hipStream_t stream_;
+};
+
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kShortDeg = 32;      // rows with <= this many kept edges go to the row-per-subgroup kernel
 constexpr int kChunk = 512;        // hub rows are cut into chunks of at most this many edges
@@ -64,6 +75,7 @@ struct Relation {
     int *hub_rows = nullptr, *hub_first = nullptr, *hub_count = nullptr;  // per hub row: first slot, #chunks
     int n_hub = 0, n_slots = 0;
     int64_t rows_owned = 0, edges_owned = 0;
+    int64_t edges_short = 0, edges_long = 0;  // owned edges by kernel (short rows / long items + hub chunks)
 };
 
 }  // namespace pea
@@ -104,6 +116,9 @@ struct AggGroup {
     int relu;
     int self_loop;       // add the i->i message (GAT/GCN)
     float neg_slope;
+    // bookkeeping for the live roofline measurement (messages reduced by the short / long launches; how many
+    // reference conv calls share this group's index read)
+    double msgs_short, msgs_long, idx_share;
 };
 
 constexpr int kMaxAggGroups = 16;

@@ -224,6 +224,7 @@ int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const C
     if (!rows) n_rows = N;
     if (n_rows <= 0) return PEA_OK;
     const int G = lanes_for_r(R);
+    ProfScope ps("fuse", stream, 4.0 * (double)n_rows * R * (P + 1));
     const unsigned blocks = (unsigned)((n_rows + (256 / G) - 1) / (256 / G));
 #define PEA_FUSE_CASE(g)                                                                                       \
     case g:                                                                                                    \
@@ -283,6 +284,7 @@ extern "C" int pea_bpr_score(int64_t B, int R, int64_t num_nodes, const float *r
     float *sums = (float *)workspace + 4;
     PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
     const size_t sh = (size_t)(2 * R * R + 2 * R) * sizeof(float);
+    pea::ProfScope ps("bpr_score", stream, (double)B * (12.0 + 12.0 * R + 4.0));
     if (blocks > 0) {
         hipLaunchKernelGGL(pea::bpr_kernel, dim3(blocks), dim3(256), sh, stream, B, R, num_nodes, repr, triples,
                            triple_stride, fc1_w, fc1_b, fc2_w, fc2_b, pos, neg, sums, err);

@@ -172,6 +172,7 @@ int launch_gemm(const GemmJob &job, const int *rows, int64_t n_rows, hipStream_t
     PEA_REQUIRE(job.n_seg > 0 && job.n_seg <= kMaxSegments, PEA_ERR_ARG, "gemm: %d segments", job.n_seg);
     if (n_rows <= 0) return PEA_OK;
     dim3 grid((unsigned)((n_rows + TM - 1) / TM), (unsigned)((job.n_out + TN - 1) / TN));
+    ProfScope ps("gemm", stream, 4.0 * (double)n_rows * (job.K1 + job.K2 + job.n_out));
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, stream, job, rows, n_rows);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
@@ -182,6 +183,7 @@ int launch_pack(const PackJob *jobs, int n_jobs, hipStream_t stream) {
         PackLaunch L;
         L.n = n_jobs - base < 24 ? n_jobs - base : 24;
         for (int i = 0; i < L.n; ++i) L.j[i] = jobs[base + i];
+        ProfScope ps("pack_weights", stream);
         hipLaunchKernelGGL(pack_kernel, dim3(L.n), dim3(256), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }

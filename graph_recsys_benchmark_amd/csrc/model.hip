@@ -44,6 +44,7 @@ struct GroupPlan {  // one aggregation group of a level
     int out_col = 0;            // column in O_s / X (GAT/GCN) or M_s (SAGE)
     size_t bias_off = 0;        // packed bias (floats from the pack base), GAT/GCN
     size_t partial_off = 0;     // floats from the partial base
+    int n_convs = 1;            // reference conv calls this group serves (index reads it saves)
 };
 
 struct Level {
@@ -257,6 +258,9 @@ int build_schedule(pea_model *m) {
                     g.last = u0.last;
                     g.out_col = (u0.last ? u0.o_col : c_beg) + (c - c_beg);
                     g.bias_off = L.bias_off + (size_t)c;
+                    g.n_convs = 0;
+                    for (size_t k = i; k < j; ++k)
+                        if (L.units[k].t_col < c + g.W && L.units[k].t_col + L.units[k].HF > c) ++g.n_convs;
                     g.partial_off = partial;
                     partial += (size_t)plan->rels[(size_t)g.rel].n_slots * partial_record_floats(g.W, g.F);
                     L.groups.push_back(g);
@@ -421,6 +425,12 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
                 a.F = g.F;
                 a.partial = partial + g.partial_off;
                 a.neg_slope = d.negative_slope;
+                {
+                    const double loops = (mode != AGG_MEAN && (plan->flags & PEA_PLAN_SELF_LOOPS)) ? 1.0 : 0.0;
+                    a.msgs_short = (double)R.edges_short + loops * R.n_short;
+                    a.msgs_long = (double)R.edges_long + loops * (R.n_long - R.n_slots);
+                    a.idx_share = mode == AGG_MEAN ? 1.0 : (double)g.n_convs;
+                }
                 if (mode == AGG_MEAN) {
                     a.feat = In + g.col;
                     a.ld_feat = (int)ldIn;

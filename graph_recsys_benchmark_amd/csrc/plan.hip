@@ -137,6 +137,7 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
         R.edges_owned += deg;
         if (deg <= kShortDeg) {
             short_rows.push_back((int)i);
+            R.edges_short += deg;
         } else if (deg <= kChunk) {
             items.push_back({(int)i, rp[(size_t)i], rp[(size_t)i + 1], -1});
         } else {
@@ -156,6 +157,7 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     std::stable_sort(items.begin(), items.end(),
                      [](const LongItem &a, const LongItem &b) { return (a.end - a.beg) > (b.end - b.beg); });
     R.max_deg = max_deg;
+    R.edges_long = R.edges_owned - R.edges_short;
     R.n_short = (int)short_rows.size();
     R.n_long = (int)items.size();
     R.n_hub = (int)hub_rows.size();

@@ -184,6 +184,15 @@ int pea_rank_eval(int64_t U, int C, int R, int64_t num_nodes, const float *repr,
                   const float *fc2_w, const float *fc2_b, float *scores, int32_t *rank, float *auc,
                   float *loss, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Live per-launch timing (bench.py's roofline leg): when enabled every kernel launch of the library is
+ * bracketed by HIP events on the caller's stream.  pea_profile_read waits for them and returns, in launch
+ * order, name (32 bytes each), milliseconds and the algorithmic bytes attributed to the launch; it clears
+ * the log.  Not for use under hipGraph capture.
+ * ---------------------------------------------------------------------------------------------- */
+int pea_profile_enable(int on);
+int pea_profile_read(int max_records, char *names_host, float *ms_host, double *bytes_host, int *count_host);
+
 #ifdef __cplusplus
 }
 #endif

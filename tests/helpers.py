@@ -108,3 +108,55 @@ def random_state_dict(model, seed, scale=0.3):
         else:
             sd[k] = torch.randn(v.shape, generator=g) * scale
     return sd
+
+
+def f64_forward(kind, sd, edges, steps, heads, channel_aggr, gcn_deg_from='row'):
+    """float64 evaluation of the same model with the torch restatement of the PyG convs
+    (oracle/pyg_restatement.py) -- the yardstick that tells fp32 summation-order noise from real error."""
+    import torch
+    from oracle import pyg_restatement as R
+    x = torch.from_numpy(sd['x']).double()
+    outs = []
+    for p, S in enumerate(steps):
+        h = x
+        for s in range(S):
+            pre = 'pea_channels.%d.gnn_layers.%d.' % (p, s)
+            lp = {k[len(pre):]: torch.from_numpy(v).double() for k, v in sd.items() if k.startswith(pre)}
+            ei = torch.from_numpy(np.ascontiguousarray(edges[p][s]))
+            last = s == S - 1
+            if kind == 'gat':
+                hh = 1 if (S > 1 and last) else heads
+                conv = R.GATConv(h.shape[1], lp['lin.weight'].shape[0] // hh, heads=hh)
+            elif kind == 'gcn':
+                conv = R.GCNConv(h.shape[1], lp['weight'].shape[1], gcn_deg_from=gcn_deg_from)
+            else:
+                conv = R.SAGEConv(h.shape[1], lp['lin_rel.weight'].shape[0])
+            conv = conv.double()
+            conv.load_state_dict(lp, strict=True)
+            with torch.no_grad():
+                h = conv(h, ei)
+                if not last:
+                    h = torch.relu(h)
+        outs.append(h)
+    stack = torch.stack(outs, dim=1)
+    if channel_aggr == 'att':
+        att = torch.from_numpy(sd['att']).double()
+        w = torch.softmax((stack * att).sum(-1), dim=-1).unsqueeze(-1)
+        fused = (stack * w).sum(1)
+    else:
+        fused = stack.mean(1)
+    return fused.numpy(), stack.numpy()
+
+
+def assert_fp32_close(got, want, truth, rtol=1e-5, atol=1e-6, what=''):
+    """Passes when `got` is elementwise within rtol/atol of `want`, OR its error against the float64 `truth`
+    is no larger than 2x the fp32 oracle's own error plus atol (different, equally valid summation orders)."""
+    got, want, truth = np.asarray(got, np.float64), np.asarray(want, np.float64), np.asarray(truth, np.float64)
+    bad = np.abs(got - want) > atol + rtol * np.abs(want)
+    if not bad.any():
+        return
+    e_got = np.abs(got - truth).max()
+    e_orc = np.abs(want - truth).max()
+    scale = np.abs(truth).max()
+    assert e_got <= 2.0 * e_orc + atol + 2e-7 * scale, \
+        '%s: %d elements off; max err vs f64: hip %.3e, fp32 oracle %.3e (scale %.3e)' % (what, bad.sum(), e_got, e_orc, scale)

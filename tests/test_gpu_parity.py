@@ -1,14 +1,16 @@
 """GPU parity: the HIP path (through the C ABI / the drop-in modules) against
   (a) the golden vectors written by the reference's own models/base.py (tests/golden), and
   (b) the C oracle (oracle/pea_oracle.c) on seeded random HINs with hub rows, multi-edges, self loops.
-Tolerance fp32: rtol 1e-5 / atol 1e-6 on small cases (config 2).  On the hub-row cases the
-oracle itself sums ~10^3-10^4 fp32 terms sequentially, so rtol is 2e-5 there (recorded reason: the two
-sides use different, equally valid fp32 summation orders; both are checked against a float64 evaluation)."""
+Tolerance fp32: rtol 1e-5 / atol 1e-6 elementwise (config 2).  On the hub-row cases the
+oracle itself sums ~10^3-10^4 fp32 terms sequentially; where an element misses the elementwise bound the test
+falls back to a float64 evaluation and requires the HIP error to be no larger than twice the fp32 oracle's own
+error (recorded reason: two different, equally valid fp32 summation orders)."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import GoldenCase, build_model, golden_cases, model_from_golden, random_hin, random_state_dict
+from helpers import (GoldenCase, assert_fp32_close, build_model, f64_forward, golden_cases, model_from_golden,
+                     random_hin, random_state_dict)
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -98,8 +100,9 @@ def test_hub_rows_multi_edges_vs_oracle(kind, heads, aggr):
     sd, cps, hls = _oracle_model(kind, model, edges, steps, heads)
     want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, hls, att=sd.get('att'), channel_aggr=aggr,
                                    return_stack=True)
-    np.testing.assert_allclose(_np(stack), wstack, rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(_np(fused), want, rtol=2e-5, atol=2e-6)
+    t_fused, t_stack = f64_forward(kind, sd, edges, steps, heads, aggr)
+    assert_fp32_close(_np(stack), wstack, t_stack, what='stack')
+    assert_fp32_close(_np(fused), want, t_fused, what='fused')
     info = model._engine.plan.relation_info(model._engine.plan.relation_of[0][0])
     assert info['hub_rows'] >= 1 and info['hub_chunks'] >= 8 and info['short_rows'] > 0 and info['long_items'] > 8
     # scoring on top
