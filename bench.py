@@ -100,14 +100,14 @@ def cpu_baseline(dataset, model, kind):
             if k.startswith('pea_channels.%d.gnn_layers.%d.' % (p, s))} for s in range(len(edges))]
     n = dataset.num_nodes
     msgs = sum(e.shape[1] + (n if kind != 'sage' else 0) for e in edges)
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), 64)
     orc.set_num_threads(cores)
     t0 = time.perf_counter()
     out = orc.channel_forward(kind, sd['x'], edges, lps, [1] * len(edges))
     dt = time.perf_counter() - t0
     return dict(value=msgs / dt, unit='edges/s', cores=cores, kind='port',
                 sample='metapath %d of %d (%s), one full-graph 2-layer channel forward, %d messages, %.1f s'
-                       % (p + 1, len(table), '+'.join(r + ('^T' if f else '') for r, f in table[p]), msgs, dt)), out
+                       % (p + 1, dataset.spec['num_metapaths'], '+'.join(r + ('^T' if f else '') for r, f in table[p]), msgs, dt)), out
 
 
 def main():

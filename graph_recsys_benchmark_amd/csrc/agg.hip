@@ -70,6 +70,23 @@ struct Soft {
 
 __device__ __forceinline__ float leaky(float a, float slope) { return a > 0.f ? a : a * slope; }
 
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// Sum of v over the F4 = F/4 consecutive lanes that hold one attention head's columns (every lane of the
+// head gets the total).  The logit (x_i.att_i).sum(-1) + (x_j.att_j).sum(-1) of GATConv.message is thus
+// computed from the gathered row itself: no per-node attention scalars are stored or gathered.
+__device__ __forceinline__ float head_sum(float v, int lane, int pos, int F4, bool pow2) {
+    if (pow2) {
+        for (int off = 1; off < F4; off <<= 1) v += __shfl_xor(v, off);
+        return v;
+    }
+    for (int off = 1; off < F4; off <<= 1) {
+        const float o = __shfl_down(v, off);
+        if (pos + off < F4) v += o;
+    }
+    return __shfl(v, lane - pos);
+}
+
 __device__ __forceinline__ int find_group(const AggLaunch &L) {
     int g = 0;
     while (g + 1 < L.n_groups && (int)blockIdx.x >= L.blk_start[g + 1]) ++g;
@@ -113,20 +130,32 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     Soft st;
     st.init();
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    int kk = 0;
+    const int lane = (int)threadIdx.x % kWave;
+    const int F4 = P.F / 4, pos = sl % F4;
+    const bool pow2 = (F4 & (F4 - 1)) == 0;
     float a_d = 0.f, di = 0.f;
+    float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
-        kk = 2 * (c4 / P.F);
-        a_d = P.a_dst[(size_t)row * P.ld_a + kk];
+        att_s = ld4(P.att_src + c4);
+        h_self = ld4(feat + (size_t)row * P.ld_feat);
+        a_d = head_sum(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
     } else if (MODE == AGG_GCN) {
         di = P.dinv[row];
     }
-    for (int e = beg; e < end; ++e) {
-        const int j = P.col[e];
+    // the subgroups of a wave walk rows of different length: keep every lane in the loop (the head sums are
+    // cross-lane) and mask finished rows instead
+    int len = end - beg;
+    if (MODE == AGG_GAT) {
+        for (int off = G; off < kWave; off <<= 1) len = max(len, __shfl_xor(len, off));
+    }
+    for (int t = 0; t < len; ++t) {
+        const int e = beg + t;
+        const bool ok = e < end;
+        const int j = ok ? P.col[e] : row;
         const float4 h = ld4(feat + (size_t)j * P.ld_feat);
         if (MODE == AGG_GAT) {
-            const float a = P.a_src[(size_t)j * P.ld_a + kk];
-            st.push(leaky(a + a_d, P.neg_slope), h);
+            const float a = head_sum(dot4(h, att_s), lane, pos, F4, pow2);
+            if (ok) st.push(leaky(a + a_d, P.neg_slope), h);
         } else if (MODE == AGG_GCN) {
             sum = fma4(P.dinv[j] * di, h, sum);
         } else {
@@ -134,12 +163,11 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
         }
     }
     if (P.self_loop) {
-        const float4 h = ld4(feat + (size_t)row * P.ld_feat);
         if (MODE == AGG_GAT) {
-            const float a = P.a_src[(size_t)row * P.ld_a + kk];
-            st.push(leaky(a + a_d, P.neg_slope), h);
+            const float a = head_sum(dot4(h_self, att_s), lane, pos, F4, pow2);
+            st.push(leaky(a + a_d, P.neg_slope), h_self);
         } else if (MODE == AGG_GCN) {
-            sum = fma4(di * di, h, sum);
+            sum = fma4(di * di, ld4(feat + (size_t)row * P.ld_feat), sum);
         }
     }
     if (active) finish_row<MODE>(P, row, c4, end - beg, st, sum);
@@ -167,34 +195,57 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     Soft st;
     st.init();
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    int kk = 0;
+    const int kk = 2 * (c4 / P.F);
+    const int F4 = P.F / 4, pos = sl % F4;
+    const bool pow2 = (F4 & (F4 - 1)) == 0;
     float a_d = 0.f, di = 0.f;
+    float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
-        kk = 2 * (c4 / P.F);
-        a_d = P.a_dst[(size_t)row * P.ld_a + kk];
+        att_s = ld4(P.att_src + c4);
+        h_self = ld4(feat + (size_t)row * P.ld_feat);
+        a_d = head_sum(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
     } else if (MODE == AGG_GCN) {
         di = P.dinv[row];
     }
+    constexpr int U = 4;  // edges in flight per subgroup: U*NSG gathered rows per wave before the first use
+    int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
     for (int base = it.beg; base < it.end; base += kWave) {
-        const int my = base + lane;
-        const int src = my < it.end ? P.col[my] : -1;
+        const int nxt = base + kWave + lane;
+        const int src_next = nxt < it.end ? P.col[nxt] : -1;  // next batch of ids is in flight during this one
         const int cnt = min(kWave, it.end - base);
-#pragma unroll 4
-        for (int t = 0; t < cnt; t += NSG) {
-            const int j = __shfl(src, t + sub);
-            const bool ok = j >= 0;
-            const int jj = ok ? j : row;
-            const float4 h = ld4(feat + (size_t)jj * P.ld_feat);
+        for (int t = 0; t < cnt; t += NSG * U) {
+            int jj[U];
+            bool ok[U];
+            float4 h[U];
+            float a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = t + u * NSG + sub;
+                const int j = __shfl(src, idx & (kWave - 1));
+                ok[u] = idx < cnt && j >= 0;
+                jj[u] = ok[u] ? j : row;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                h[u] = ld4(feat + (size_t)jj[u] * P.ld_feat);
+                if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
+            }
             if (MODE == AGG_GAT) {
-                const float a = P.a_src[(size_t)jj * P.ld_a + kk];
-                if (ok) st.push(leaky(a + a_d, P.neg_slope), h);
-            } else if (MODE == AGG_GCN) {
-                const float w = ok ? P.dinv[jj] * di : 0.f;
-                sum = fma4(w, h, sum);
-            } else {
-                if (ok) sum = add4(sum, h);
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[u] = head_sum(dot4(h[u], att_s), lane, pos, F4, pow2);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (MODE == AGG_GAT) {
+                    if (ok[u]) st.push(leaky(a[u] + a_d, P.neg_slope), h[u]);
+                } else if (MODE == AGG_GCN) {
+                    sum = fma4(ok[u] ? a[u] * di : 0.f, h[u], sum);
+                } else {
+                    if (ok[u]) sum = add4(sum, h[u]);
+                }
             }
         }
+        src = src_next;
     }
     // fold the NSG subgroup states (xor butterfly: every lane ends with the same value)
 #pragma unroll
@@ -224,12 +275,11 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
         return;
     }
     if (P.self_loop) {
-        const float4 h = ld4(feat + (size_t)row * P.ld_feat);
         if (MODE == AGG_GAT) {
-            const float a = P.a_src[(size_t)row * P.ld_a + kk];
-            st.push(leaky(a + a_d, P.neg_slope), h);
+            const float a = head_sum(dot4(h_self, att_s), lane, pos, F4, pow2);
+            st.push(leaky(a + a_d, P.neg_slope), h_self);
         } else if (MODE == AGG_GCN) {
-            sum = fma4(di * di, h, sum);
+            sum = fma4(di * di, ld4(feat + (size_t)row * P.ld_feat), sum);
         }
     }
     if (sub == 0 && active) finish_row<MODE>(P, row, c4, it.end - it.beg, st, sum);
@@ -282,8 +332,10 @@ __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
     if (P.self_loop) {
         const float4 h = ld4(feat + (size_t)row * P.ld_feat);
         if (MODE == AGG_GAT) {
-            const float a_d = P.a_dst[(size_t)row * P.ld_a + kk];
-            const float a = P.a_src[(size_t)row * P.ld_a + kk];
+            const int F4 = P.F / 4, pos = sl % F4;
+            const bool pow2 = (F4 & (F4 - 1)) == 0;
+            const float a_d = head_sum(dot4(h, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
+            const float a = head_sum(dot4(h, ld4(P.att_src + c4)), lane, pos, F4, pow2);
             st.push(leaky(a + a_d, P.neg_slope), h);
         } else if (MODE == AGG_GCN) {
             const float di = P.dinv[row];

@@ -104,13 +104,13 @@ struct AggGroup {
     const int *hub_rows, *hub_first, *hub_count;
     int n_short, n_long, n_hub;
     const float *feat;   // gather source; row j at feat + j*ld_feat
-    const float *a_src;  // GAT: a_src[j*ld_a + k]
-    const float *a_dst;  // GAT: a_dst[i*ld_a + k]
+    const float *att_src;  // GAT: att_j flattened over the group's columns [W] (multiplies the SOURCE row)
+    const float *att_dst;  // GAT: att_i flattened [W] (multiplies the TARGET row)
     const float *dinv;   // GCN
     const float *bias;   // [W] or null
     float *out;          // row i at out + i*ld_out
     float *partial;      // hub partial records
-    int ld_feat, ld_a, ld_out;
+    int ld_feat, ld_out;
     int W;               // columns of this group (multiple of 4, <= 256)
     int F;               // columns per attention group (GAT), W % F == 0
     int relu;
@@ -145,6 +145,7 @@ struct GemmJob {
     GemmSegment seg[kMaxSegments];
 };
 int launch_gemm(const GemmJob &job, const int *rows, int64_t n_rows, hipStream_t stream);
+int launch_gemm_batch(const GemmJob *jobs, int n_jobs, const int *rows, int64_t n_rows, hipStream_t stream);
 
 // weight packing: produces the k-major extended weight blocks the GEMM consumes
 struct PackJob {
@@ -155,9 +156,9 @@ struct PackJob {
     const float *w3;     // bias source [HF] (GAT bias | GCN bias | SAGE lin_rel.bias), may be null -> zeros
     float *B;            // destination block start (column offset already applied), row stride ldb
     float *bias;         // destination bias block [HF]
+    float *att_src, *att_dst;  // GAT: destination blocks [HF] for att_j / att_i
     int ldb;
     int in, HF, F;       // input width, output width, width per attention group
-    int a_col;           // GAT: column (relative to B) where this layer's 2*heads attention columns start
     int zero_col, zero_n;  // padding columns (relative to B) to clear in every k row
 };
 int launch_pack(const PackJob *jobs_host, int n_jobs, hipStream_t stream);

@@ -4,112 +4,117 @@
 //
 // The weights of every layer are re-packed each forward (they change every optimizer step) into
 // k-major blocks  B[k][col]  so one GEMM job can serve several channels that share the same input
-// (all P first-layer channels read the same x, models/base.py:192-193).  For GAT the two attention
-// projections are folded into the GEMM as extra output columns:
-//     a_src[n,h] = sum_f att_j[h,f] * (W x_n)[h,f] = x_n . (W_h^T att_j[h])      (likewise a_dst / att_i)
-// so the per-edge logits need one scalar per endpoint and no [M, F] temporaries.
+// (all P first-layer channels read the same x, models/base.py:192-193).
 //
-// fp32 VALU kernel, 64x64 output tile per 256-thread block, 4x4 micro-tile per thread, operands staged
-// through LDS in k-chunks of 64.  (The transforms are ~10 % of the forward's bytes; MFMA f32 is a later step.)
+// f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain): one wave owns a 32-row
+// tile, keeps its A fragment in registers (lane (r, h) holds A[row r][k in h*KH .. h*KH+KH) -- the k order is
+// permuted identically on the B side, which a sum over k does not care about) and walks the job's 32-column tiles,
+// streaming the k-major B columns from L2.  No LDS, no barriers; 4 independent waves per block.
 #include "common.h"
 
 namespace pea {
 namespace {
 
-constexpr int TM = 64, TN = 64, TK = 64, LDS_LD = 68;  // 68 floats: keeps float4 alignment, breaks bank stride
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxBatch = 12;
+struct GemmBatch {
+    int n;
+    GemmJob j[kMaxBatch];
+};
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-__device__ __forceinline__ void store_cols(const GemmJob &J, int64_t orow, int c, float4 v) {
-    float vv[4] = {v.x, v.y, v.z, v.w};
-    // fast path: the four columns sit inside one segment, 16-byte aligned at the destination
-    for (int s = 0; s < J.n_seg; ++s) {
-        const GemmSegment &S = J.seg[s];
-        if (c >= S.c0 && c + 4 <= S.c1 && ((c - S.c0) & 3) == 0 && (S.ld & 3) == 0) {
-            if (S.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            *reinterpret_cast<float4 *>(S.dst + orow * S.ld + (c - S.c0)) = v;
-            return;
-        }
-    }
-    for (int i = 0; i < 4; ++i) {
-        const int cc = c + i;
-        for (int s = 0; s < J.n_seg; ++s) {
-            const GemmSegment &S = J.seg[s];
-            if (cc >= S.c0 && cc < S.c1) {
-                S.dst[orow * S.ld + (cc - S.c0)] = S.relu ? fmaxf(vv[i], 0.f) : vv[i];
-                break;
-            }
-        }
+template <int KH>
+__device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, int kbase, float (&a)[KH]) {
+    const int K = J.K1 + J.K2;
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+        const int k = kbase + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rv && k < K) v = k < J.K1 ? ld4(J.A1 + srow * J.lda1 + k) : ld4(J.A2 + srow * J.lda2 + (k - J.K1));
+        a[q * 4 + 0] = v.x;
+        a[q * 4 + 1] = v.y;
+        a[q * 4 + 2] = v.z;
+        a[q * 4 + 3] = v.w;
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmJob J, const int *__restrict__ rows, int64_t n_rows) {
-    __shared__ float As[TK][LDS_LD];
-    __shared__ float Bs[TK][LDS_LD];
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * TM;
-    const int col0 = blockIdx.y * TN;
+// 4 waves = 4 row tiles per block share each 32-column B tile through a double-buffered LDS image
+// (one barrier per stage; the next tile's global loads are in flight during the MFMAs).
+template <int KH>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmBatch Bt, const int *__restrict__ rows, int64_t n_rows) {
+    __shared__ float Bs[2][2 * KH][32];
+    constexpr int NLD = (2 * KH * 32 / 4) / 256;  // float4 loads per thread per B tile
+    const GemmJob &J = Bt.j[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * 32;
+    const int64_t grow = row0 + r;
+    const bool rv = grow < n_rows;
+    const int64_t srow = rv ? (rows ? (int64_t)rows[grow] : grow) : 0;
     const int K = J.K1 + J.K2;
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int nkc = (K + 2 * KH - 1) / (2 * KH), nct = (J.n_out + 31) / 32;
+    const int n_stage = nkc * nct;
+    float a[KH];
+    if (nkc == 1) load_a<KH>(J, srow, rv, h * KH, a);
 
-    for (int kc = 0; kc < K; kc += TK) {
+    float4 pre[NLD];
+    auto fetch = [&](int stage) {
+        const int col0 = (stage / nkc) * 32, kc = (stage % nkc) * 2 * KH;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
-            const int r = idx >> 4, kq = idx & 15;
-            const int64_t grow = row0 + r;
-            const int k = kc + kq * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow < n_rows && k < K) {
-                const int64_t srow = rows ? rows[grow] : grow;
-                v = k < J.K1 ? ld4(J.A1 + srow * J.lda1 + k) : ld4(J.A2 + srow * J.lda2 + (k - J.K1));
+            const int k = kc + idx / 8, c = col0 + (idx & 7) * 4;
+            pre[i] = (k < K && c < J.ldb) ? ld4(J.B + (size_t)k * J.ldb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<float4 *>(&Bs[buf][idx / 8][(idx & 7) * 4]) = pre[i];
+        }
+    };
+    fetch(0);
+    stash(0);
+    f32x16 acc;
+    for (int s = 0; s < n_stage; ++s) {
+        __syncthreads();
+        const int col0 = (s / nkc) * 32, kci = s % nkc;
+        if (s + 1 < n_stage) fetch(s + 1);
+        if (kci == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        }
+        if (nkc > 1) load_a<KH>(J, srow, rv, kci * 2 * KH + h * KH, a);
+        const float *bs = &Bs[s & 1][h * KH][r];
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bs[kk * 32], acc, 0, 0, 0);
+        if (kci == nkc - 1) {
+            // epilogue: this lane owns column c of rows (reg&3) + 8*(reg>>2) + 4*h
+            const int c = col0 + r;
+            float *dst = nullptr;
+            int ld = 0, relu = 0;
+            for (int sg = 0; sg < J.n_seg; ++sg)
+                if (c >= J.seg[sg].c0 && c < J.seg[sg].c1) {
+                    dst = J.seg[sg].dst + (c - J.seg[sg].c0);
+                    ld = J.seg[sg].ld;
+                    relu = J.seg[sg].relu;
+                }
+            if (dst) {
+                const float bias = J.bias ? J.bias[c] : 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t g = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    if (g >= n_rows) continue;
+                    const int64_t orow = rows ? (int64_t)rows[g] : g;
+                    float v = acc[reg] + bias;
+                    if (relu) v = fmaxf(v, 0.f);
+                    dst[orow * ld] = v;
+                }
             }
-            As[kq * 4 + 0][r] = v.x;
-            As[kq * 4 + 1][r] = v.y;
-            As[kq * 4 + 2][r] = v.z;
-            As[kq * 4 + 3][r] = v.w;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256;
-            const int k = idx >> 4, cq = idx & 15;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kc + k < K && col0 + cq * 4 < J.n_out) v = ld4(J.B + (size_t)(kc + k) * J.ldb + col0 + cq * 4);
-            *reinterpret_cast<float4 *>(&Bs[k][cq * 4]) = v;
-        }
-        __syncthreads();
-        const int kn = min(TK, K - kc);
-#pragma unroll 8
-        for (int k = 0; k < kn; ++k) {
-            const float4 a = *reinterpret_cast<const float4 *>(&As[k][ty * 4]);
-            const float4 b = *reinterpret_cast<const float4 *>(&Bs[k][tx * 4]);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-            const float bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-    const int c = col0 + tx * 4;
-    if (c >= J.n_out) return;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (J.bias) bias = ld4(J.bias + c);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t grow = row0 + ty * 4 + i;
-        if (grow >= n_rows) continue;
-        const int64_t orow = rows ? rows[grow] : grow;
-        store_cols(J, orow, c,
-                   make_float4(acc[i][0] + bias.x, acc[i][1] + bias.y, acc[i][2] + bias.z, acc[i][3] + bias.w));
+        if (s + 1 < n_stage) stash((s + 1) & 1);
     }
 }
 
@@ -128,17 +133,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackLaunch L) {
             const int o = idx / J.in, k = idx % J.in;
             J.B[(size_t)k * J.ldb + o] = J.w0[idx];
         }
-        const int heads = J.HF / J.F;
-        for (int idx = tid; idx < heads * J.in; idx += 256) {
-            const int h = idx / J.in, k = idx % J.in;
-            float vs = 0.f, vd = 0.f;
-            for (int f = 0; f < J.F; ++f) {
-                const float w = J.w0[(size_t)(h * J.F + f) * J.in + k];
-                vd = fmaf(J.w1[h * J.F + f], w, vd);  // att_i multiplies the TARGET row
-                vs = fmaf(J.w2[h * J.F + f], w, vs);  // att_j multiplies the SOURCE row
-            }
-            J.B[(size_t)k * J.ldb + J.a_col + 2 * h] = vs;
-            J.B[(size_t)k * J.ldb + J.a_col + 2 * h + 1] = vd;
+        for (int o = tid; o < J.HF; o += 256) {
+            J.att_dst[o] = J.w1[o];  // att_i multiplies the TARGET row
+            J.att_src[o] = J.w2[o];  // att_j multiplies the SOURCE row
         }
     } else if (J.kind == PEA_KIND_GCN) {
         for (int idx = tid; idx < J.in * J.HF; idx += 256) {
@@ -162,20 +159,54 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackLaunch L) {
 
 }  // namespace
 
-int launch_gemm(const GemmJob &job, const int *rows, int64_t n_rows, hipStream_t stream) {
+static int check_job(const GemmJob &job) {
     PEA_REQUIRE(job.K1 > 0 && job.K1 % 4 == 0 && job.K2 % 4 == 0, PEA_ERR_ARG,
                 "gemm: input widths (%d, %d) must be multiples of 4", job.K1, job.K2);
-    PEA_REQUIRE(job.n_out > 0 && job.n_out % 4 == 0 && job.ldb % 4 == 0 && job.ldb >= job.n_out, PEA_ERR_ARG,
-                "gemm: output width %d / ldb %d must be multiples of 4", job.n_out, job.ldb);
+    PEA_REQUIRE(job.n_out > 0 && job.ldb >= job.n_out, PEA_ERR_ARG, "gemm: output width %d / ldb %d", job.n_out, job.ldb);
     PEA_REQUIRE(job.lda1 % 4 == 0 && (job.K2 == 0 || job.lda2 % 4 == 0), PEA_ERR_ARG,
                 "gemm: input row strides must be multiples of 4 floats");
     PEA_REQUIRE(job.n_seg > 0 && job.n_seg <= kMaxSegments, PEA_ERR_ARG, "gemm: %d segments", job.n_seg);
-    if (n_rows <= 0) return PEA_OK;
-    dim3 grid((unsigned)((n_rows + TM - 1) / TM), (unsigned)((job.n_out + TN - 1) / TN));
-    ProfScope ps("gemm", stream, 4.0 * (double)n_rows * (job.K1 + job.K2 + job.n_out));
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, stream, job, rows, n_rows);
-    PEA_HIP(hipGetLastError());
     return PEA_OK;
+}
+
+// Jobs of one call share the row set; jobs with the same k-depth class go out as one launch (grid.y = job).
+int launch_gemm_batch(const GemmJob *jobs, int n_jobs, const int *rows, int64_t n_rows, hipStream_t stream) {
+    if (n_rows <= 0 || n_jobs <= 0) return PEA_OK;
+    for (int i = 0; i < n_jobs; ++i) PEA_TRY(check_job(jobs[i]));
+    const int classes[3] = {16, 32, 64};
+    for (int ci = 0; ci < 3; ++ci) {
+        GemmBatch Bt;
+        Bt.n = 0;
+        double bytes = 0.0;
+        auto flush = [&]() -> int {
+            if (Bt.n == 0) return PEA_OK;
+            dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)Bt.n);
+            ProfScope ps(Bt.n == 1 ? "gemm_mfma_shared" : "gemm_mfma_batch", stream, bytes);
+            switch (classes[ci]) {
+                case 16: hipLaunchKernelGGL(gemm_mfma_kernel<16>, grid, dim3(256), 0, stream, Bt, rows, n_rows); break;
+                case 32: hipLaunchKernelGGL(gemm_mfma_kernel<32>, grid, dim3(256), 0, stream, Bt, rows, n_rows); break;
+                default: hipLaunchKernelGGL(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows); break;
+            }
+            PEA_HIP(hipGetLastError());
+            Bt.n = 0;
+            bytes = 0.0;
+            return PEA_OK;
+        };
+        for (int i = 0; i < n_jobs; ++i) {
+            const int K = jobs[i].K1 + jobs[i].K2;
+            const int cls = K <= 32 ? 16 : K <= 64 ? 32 : 64;  // k per lane half; deeper K loops in chunks of 128
+            if (cls != classes[ci]) continue;
+            Bt.j[Bt.n++] = jobs[i];
+            bytes += 4.0 * (double)n_rows * (K + jobs[i].n_out);
+            if (Bt.n == kMaxBatch) PEA_TRY(flush());
+        }
+        PEA_TRY(flush());
+    }
+    return PEA_OK;
+}
+
+int launch_gemm(const GemmJob &job, const int *rows, int64_t n_rows, hipStream_t stream) {
+    return launch_gemm_batch(&job, 1, rows, n_rows, stream);
 }
 
 int launch_pack(const PackJob *jobs, int n_jobs, hipStream_t stream) {

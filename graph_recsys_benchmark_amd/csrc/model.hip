@@ -10,10 +10,9 @@
 //     columns sit side by side, so the relation's index array is read once and a gathered row is one
 //     contiguous run (7 of the 9 MovieLens metapaths end in flip(user2item),
 //     utils/general_utils.py:300-307 / 335-343);
-//   - the GAT attention projections ride along as extra GEMM columns (gemm.hip).
 // Buffers (row-major fp32, row strides multiples of 4 floats), per level s:
-//   GAT/GCN : T_s [N, sum HF] transformed features (gather source), A_s [N, 2*sum heads] (a_src, a_dst
-//             interleaved per head), O_s [N, sum HF] relu(conv) output = input of level s+1
+//   GAT/GCN : T_s [N, sum HF] transformed features (gather source; the GAT logits are computed from the
+//             gathered rows, agg.hip), O_s [N, sum HF] relu(conv) output = input of level s+1
 //   SAGE    : M_s [N, ...] neighbour means of the level's input, O_s [N, sum F]
 //   X [N, P*R]: last-layer outputs of every channel (the "stack" the fusion reads).
 #include <algorithm>
@@ -55,6 +54,7 @@ struct Level {
     size_t off_t = 0, off_a = 0, off_o = 0;  // float offsets in the workspace
     bool shared_input = false;               // level 0 of GAT/GCN: one concatenated GEMM job
     size_t b_off = 0, bias_off = 0;          // concatenated weight block / per-level bias block
+    size_t att_src_off = 0, att_dst_off = 0; // per-level att_j / att_i rows in column order (GAT)
     int ldb = 0, n_out = 0;
 };
 
@@ -145,7 +145,7 @@ int build_schedule(pea_model *m) {
         L.n_cols = col;
         L.n_heads = ak;
         L.ld_t = pad4(col);
-        L.ld_a = gat ? pad4(2 * ak) : 0;
+        L.ld_a = 0;
         // outputs of channels that continue: GAT/GCN keep the T_s column order; SAGE lays O_s out in the order the
         // NEXT level aggregates it (same relation side by side)
         std::vector<Unit *> cont;
@@ -176,7 +176,7 @@ int build_schedule(pea_model *m) {
         // packed weights + biases
         L.shared_input = !sage && s == 0;
         if (L.shared_input) {
-            L.n_out = pad4(L.n_cols + (gat ? 2 * L.n_heads : 0));
+            L.n_out = pad4(L.n_cols);
             L.ldb = L.n_out;
             L.b_off = pack;
             pack += (size_t)d.emb_dim * (size_t)L.ldb;
@@ -187,7 +187,7 @@ int build_schedule(pea_model *m) {
         } else {
             for (Unit &u : L.units) {
                 const int K = sage ? 2 * u.in_w : u.in_w;
-                u.ldb = pad4(u.HF + (gat ? 2 * u.heads : 0));
+                u.ldb = pad4(u.HF);
                 u.b_off = pack;
                 pack += (size_t)K * (size_t)u.ldb;
             }
@@ -201,6 +201,12 @@ int build_schedule(pea_model *m) {
             L.bias_off = pack;
             pack += (size_t)L.ld_t;
             for (Unit &u : L.units) u.bias_off = L.bias_off + (size_t)u.t_col;
+            if (gat) {
+                L.att_src_off = pack;
+                pack += (size_t)L.ld_t;
+                L.att_dst_off = pack;
+                pack += (size_t)L.ld_t;
+            }
         }
         // aggregation groups
         size_t partial = 0;
@@ -375,7 +381,8 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
                 j.w2 = param(u, 2);
                 j.w3 = param(u, 3);
                 PEA_REQUIRE(j.w1 && j.w2, PEA_ERR_ARG, "forward: null att_i/att_j (channel %d step %d)", u.p, u.s);
-                j.a_col = L.shared_input ? (L.n_cols + 2 * u.a_k - u.t_col) : u.HF;
+                j.att_src = pack + L.att_src_off + u.t_col;
+                j.att_dst = pack + L.att_dst_off + u.t_col;
             } else if (kind == PEA_KIND_GCN) {
                 j.w3 = param(u, 1);
             } else {
@@ -385,12 +392,12 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
             }
             if (L.shared_input) {  // the last unit clears the block's padding columns
                 if (ui + 1 == L.units.size()) {
-                    const int used = L.n_cols + (kind == PEA_KIND_GAT ? 2 * L.n_heads : 0);
+                    const int used = L.n_cols;
                     j.zero_col = used - u.t_col;
                     j.zero_n = L.n_out - used;
                 }
             } else {
-                const int used = u.HF + (kind == PEA_KIND_GAT ? 2 * u.heads : 0);
+                const int used = u.HF;
                 j.zero_col = used;
                 j.zero_n = u.ldb - used;
             }
@@ -402,7 +409,7 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
     // ---- 2. levels ----
     for (size_t s = 0; s < m->levels.size(); ++s) {
         Level &L = m->levels[s];
-        float *T = wsf + L.off_t, *A = wsf + L.off_a, *O = wsf + L.off_o;
+        float *T = wsf + L.off_t, *O = wsf + L.off_o;
         const float *In = s == 0 ? x : wsf + m->levels[s - 1].off_o;
         const int64_t ldIn = s == 0 ? ldx : m->levels[s - 1].ld_o;
 
@@ -439,9 +446,8 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
                 } else {
                     a.feat = T + g.col;
                     a.ld_feat = L.ld_t;
-                    a.a_src = A + 2 * g.a_k;
-                    a.a_dst = A + 2 * g.a_k + 1;
-                    a.ld_a = L.ld_a;
+                    a.att_src = pack + L.att_src_off + g.col;
+                    a.att_dst = pack + L.att_dst_off + g.col;
                     a.bias = pack + g.bias_off;
                     a.self_loop = (plan->flags & PEA_PLAN_SELF_LOOPS) ? 1 : 0;
                     if (g.last) {
@@ -467,6 +473,7 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
 
         if (kind == PEA_KIND_SAGE) {
             PEA_TRY(run_groups(AGG_MEAN));
+            std::vector<GemmJob> jobs;
             for (const Unit &u : L.units) {
                 GemmJob J{};
                 J.A1 = T + u.t_col;
@@ -491,8 +498,9 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
                     J.seg[0].ld = L.ld_o;
                     J.seg[0].relu = 1;
                 }
-                PEA_TRY(launch_gemm(J, nullptr, N, stream));
+                jobs.push_back(J);
             }
+            PEA_TRY(launch_gemm_batch(jobs.data(), (int)jobs.size(), nullptr, N, stream));
         } else {
             if (L.shared_input) {
                 GemmJob J{};
@@ -507,15 +515,9 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
                 J.seg[0].c1 = L.n_cols;
                 J.seg[0].dst = T;
                 J.seg[0].ld = L.ld_t;
-                if (kind == PEA_KIND_GAT) {
-                    J.n_seg = 2;
-                    J.seg[1].c0 = L.n_cols;
-                    J.seg[1].c1 = L.n_cols + 2 * L.n_heads;
-                    J.seg[1].dst = A;
-                    J.seg[1].ld = L.ld_a;
-                }
                 PEA_TRY(launch_gemm(J, nullptr, N, stream));
             } else {
+                std::vector<GemmJob> jobs;
                 for (const Unit &u : L.units) {
                     GemmJob J{};
                     J.A1 = In + u.in_col;
@@ -529,15 +531,9 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
                     J.seg[0].c1 = u.HF;
                     J.seg[0].dst = T + u.t_col;
                     J.seg[0].ld = L.ld_t;
-                    if (kind == PEA_KIND_GAT) {
-                        J.n_seg = 2;
-                        J.seg[1].c0 = u.HF;
-                        J.seg[1].c1 = u.HF + 2 * u.heads;
-                        J.seg[1].dst = A + 2 * u.a_k;
-                        J.seg[1].ld = L.ld_a;
-                    }
-                    PEA_TRY(launch_gemm(J, nullptr, N, stream));
+                    jobs.push_back(J);
                 }
+                PEA_TRY(launch_gemm_batch(jobs.data(), (int)jobs.size(), nullptr, N, stream));
             }
             PEA_TRY(run_groups(kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
         }
