@@ -81,6 +81,10 @@ namespace pea {
 namespace {
 
 int pad4(int v) { return (v + 3) & ~3; }
+// row strides of the big node-major buffers are whole 128-byte cache lines and every buffer starts on a 256-byte
+// boundary, so a gathered 256-byte row chunk touches 2 lines, never 3
+int pad_ld(int v) { return (v + 31) & ~31; }
+size_t pad_off(size_t v) { return (v + 63) & ~(size_t)63; }
 
 int width_out(const pea_model_desc &d, int S, int s, int *heads_out) {
     // PEA{GAT,GCN,Sage}Channel (models/peagat.py:14-21): 1 step: emb -> repr with num_heads heads;
@@ -144,7 +148,7 @@ int build_schedule(pea_model *m) {
         }
         L.n_cols = col;
         L.n_heads = ak;
-        L.ld_t = pad4(col);
+        L.ld_t = pad_ld(col);
         L.ld_a = 0;
         // outputs of channels that continue: GAT/GCN keep the T_s column order; SAGE lays O_s out in the order the
         // NEXT level aggregates it (same relation side by side)
@@ -162,7 +166,7 @@ int build_schedule(pea_model *m) {
             in_w[(size_t)u->p] = u->HF;
             in_col[(size_t)u->p] = u->o_col;
         }
-        L.ld_o = sage ? pad4(ocol) : L.ld_t;
+        L.ld_o = sage ? pad_ld(ocol) : L.ld_t;
         for (Unit &u : L.units) {
             if (!u.last) continue;
             u.o_col = x_cols;
@@ -246,7 +250,7 @@ int build_schedule(pea_model *m) {
                 mcol += c_end - c_beg;
                 i = j;
             }
-            L.ld_t = pad4(mcol);
+            L.ld_t = pad_ld(mcol);
         } else {
             while (i < L.units.size()) {
                 const Unit &u0 = L.units[i];
@@ -276,11 +280,10 @@ int build_schedule(pea_model *m) {
         }
         partial_max = std::max(partial_max, partial);
         L.off_t = ws;
-        ws += (size_t)N * (size_t)L.ld_t;
+        ws = pad_off(ws + (size_t)N * (size_t)L.ld_t);
         L.off_a = ws;
-        ws += (size_t)N * (size_t)L.ld_a;
         L.off_o = ws;
-        ws += (size_t)N * (size_t)L.ld_o;
+        ws = pad_off(ws + (size_t)N * (size_t)L.ld_o);
         // statistics: messages and the algorithmic-byte yardstick of SURVEY.md 8(d)
         for (const Unit &u : L.units) {
             const Relation &R = plan->rels[(size_t)u.rel];
@@ -296,9 +299,9 @@ int build_schedule(pea_model *m) {
             }
         }
     }
-    m->ld_x = pad4(x_cols);
+    m->ld_x = pad_ld(x_cols);
     m->alg_bytes += 4.0 * (double)N * P * d.repr_dim + 4.0 * (double)N * d.repr_dim;
-    m->pack_floats = (pack + 3) & ~(size_t)3;
+    m->pack_floats = pad_off(pack);
     size_t off = m->pack_floats;
     for (Level &L : m->levels) {
         L.off_t += off;
@@ -307,7 +310,7 @@ int build_schedule(pea_model *m) {
     }
     off += ws;
     m->off_x = off;
-    off += (size_t)N * (size_t)m->ld_x;
+    off = pad_off(off + (size_t)N * (size_t)m->ld_x);
     m->off_partial = off;
     m->partial_floats = (partial_max + 3) & ~(size_t)3;
     off += m->partial_floats;
@@ -570,7 +573,7 @@ extern "C" int pea_model_destroy(pea_model *model) {
 }
 
 extern "C" size_t pea_model_workspace_bytes(const pea_model *model) {
-    return model ? model->total_floats * sizeof(float) + 64 : 0;
+    return model ? model->total_floats * sizeof(float) + 256 : 0;
 }
 
 extern "C" int pea_model_params_per_layer(const pea_model *model) { return model ? model->n_slots_per_layer : 0; }
@@ -583,7 +586,7 @@ extern "C" int pea_model_stats(const pea_model *model, int64_t *messages, double
 }
 
 static float *aligned_ws(void *workspace) {
-    return reinterpret_cast<float *>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    return reinterpret_cast<float *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
 }
 
 extern "C" int pea_model_forward(pea_model *model, const float *const *params_host, const float *x, const float *att,
@@ -621,13 +624,13 @@ static int single_conv(int kind, const pea_plan *plan, int relation, int in_chan
     d.negative_slope = slope;
     PEA_TRY(init_model(&m, plan, &d));
     if (bytes_only) {
-        *bytes_only = m.total_floats * sizeof(float) + 64;
+        *bytes_only = m.total_floats * sizeof(float) + 256;
         return PEA_OK;
     }
     PEA_REQUIRE(x && out && workspace, PEA_ERR_ARG, "conv: null argument");
     PEA_REQUIRE(ldx >= in_channels && ldx % 4 == 0 && ldo >= (int64_t)heads * out_channels && ldo % 4 == 0, PEA_ERR_ARG,
                 "conv: row strides (%lld, %lld) must be multiples of 4 covering the row", (long long)ldx, (long long)ldo);
-    PEA_REQUIRE(workspace_bytes >= m.total_floats * sizeof(float) + 64, PEA_ERR_NOMEM, "conv: workspace too small");
+    PEA_REQUIRE(workspace_bytes >= m.total_floats * sizeof(float) + 256, PEA_ERR_NOMEM, "conv: workspace too small");
     return model_forward(&m, params, x, ldx, nullptr, -1, aligned_ws(workspace), nullptr, nullptr, out, ldo, relu,
                          (hipStream_t)stream);
 }
