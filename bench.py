@@ -130,7 +130,7 @@ def main():
     model.train()
     batch = torch.from_numpy(dataset.bpr_batch()).to(device)
     if world > 1:
-        model.shard(rank, world)
+        model.shard(rank, world)     # destination rows tile-interleaved over the ranks; exchanges over RCCL
 
     def step():
         with torch.no_grad():

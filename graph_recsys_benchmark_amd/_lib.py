@@ -31,6 +31,12 @@ class ModelDesc(C.Structure):
                 ('gcn_deg_from_col', C.c_int), ('negative_slope', C.c_float)]
 
 
+class ExchangeDesc(C.Structure):
+    _fields_ = [('relation', C.c_int), ('slots_per_rank', C.c_int64), ('width', C.c_int), ('dst_ld', C.c_int),
+                ('dst_offset_bytes', C.c_size_t), ('src_offset_bytes', C.c_size_t), ('src_ld', C.c_int),
+                ('src_col', C.c_int)]
+
+
 # every symbol include/peahip.h declares: name -> (restype, argtypes)
 _vp, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 SIGNATURES = {
@@ -46,6 +52,12 @@ SIGNATURES = {
     'pea_model_workspace_bytes': (_sz, [_vp]),
     'pea_model_params_per_layer': (_int, [_vp]),
     'pea_model_forward': (_int, [_vp, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
+    'pea_plan_set_owned_rows': (_int, [_vp, _vp, _i64, _vp]),
+    'pea_plan_set_sources': (_int, [_vp, _int, _vp, _i64, _vp, _i64, _vp]),
+    'pea_model_num_stages': (_int, [_vp]),
+    'pea_model_forward_stage': (_int, [_vp, _int, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
+    'pea_model_num_exchanges': (_int, [_vp, _int]),
+    'pea_model_exchange_desc': (_int, [_vp, _int, _int, C.POINTER(ExchangeDesc)]),
     'pea_model_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
     'pea_conv_workspace_bytes': (_sz, [_vp, _int, _int, _int, _int, _int]),
     'pea_gat_conv': (_int, [_vp, _int, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, C.c_float, _int, _vp, _i64, _vp, _sz, _vp]),

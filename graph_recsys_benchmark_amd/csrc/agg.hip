@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     const int beg = P.rowptr[row];
     const int end = valid ? P.rowptr[row + 1] : beg;
     const float *feat = P.feat + c4;
+    const float *feat_self = P.feat_self + c4;
 
     Soft st;
     st.init();
@@ -137,10 +138,10 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
         att_s = ld4(P.att_src + c4);
-        h_self = ld4(feat + (size_t)row * P.ld_feat);
+        h_self = ld4(feat_self + (size_t)row * P.ld_self);
         a_d = head_sum(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
     } else if (MODE == AGG_GCN) {
-        di = P.dinv[row];
+        di = P.dinv_self[row];
     }
     // the subgroups of a wave walk rows of different length: keep every lane in the loop (the head sums are
     // cross-lane) and mask finished rows instead
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     for (int t = 0; t < len; ++t) {
         const int e = beg + t;
         const bool ok = e < end;
-        const int j = ok ? P.col[e] : row;
+        const int j = ok ? P.col[e] : 0;
         const float4 h = ld4(feat + (size_t)j * P.ld_feat);
         if (MODE == AGG_GAT) {
             const float a = head_sum(dot4(h, att_s), lane, pos, F4, pow2);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
             const float a = head_sum(dot4(h_self, att_s), lane, pos, F4, pow2);
             st.push(leaky(a + a_d, P.neg_slope), h_self);
         } else if (MODE == AGG_GCN) {
-            sum = fma4(di * di, ld4(feat + (size_t)row * P.ld_feat), sum);
+            sum = fma4(di * di, ld4(feat_self + (size_t)row * P.ld_self), sum);
         }
     }
     if (active) finish_row<MODE>(P, row, c4, end - beg, st, sum);
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     const bool active = sl * 4 < P.W;
     const int c4 = active ? sl * 4 : 0;
     const float *feat = P.feat + c4;
+    const float *feat_self = P.feat_self + c4;
     const int row = it.row;
 
     Soft st;
@@ -202,10 +204,10 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
         att_s = ld4(P.att_src + c4);
-        h_self = ld4(feat + (size_t)row * P.ld_feat);
+        h_self = ld4(feat_self + (size_t)row * P.ld_self);
         a_d = head_sum(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
     } else if (MODE == AGG_GCN) {
-        di = P.dinv[row];
+        di = P.dinv_self[row];
     }
     constexpr int U = 4;  // edges in flight per subgroup: U*NSG gathered rows per wave before the first use
     int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
                 const int idx = t + u * NSG + sub;
                 const int j = __shfl(src, idx & (kWave - 1));
                 ok[u] = idx < cnt && j >= 0;
-                jj[u] = ok[u] ? j : row;
+                jj[u] = ok[u] ? j : 0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
             const float a = head_sum(dot4(h_self, att_s), lane, pos, F4, pow2);
             st.push(leaky(a + a_d, P.neg_slope), h_self);
         } else if (MODE == AGG_GCN) {
-            sum = fma4(di * di, ld4(feat + (size_t)row * P.ld_feat), sum);
+            sum = fma4(di * di, ld4(feat_self + (size_t)row * P.ld_self), sum);
         }
     }
     if (sub == 0 && active) finish_row<MODE>(P, row, c4, it.end - it.beg, st, sum);
@@ -328,9 +330,9 @@ __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
             sum = add4(sum, shfl_xor4(sum, off));
         }
     }
-    const float *feat = P.feat + c4;
+    const float *feat_self = P.feat_self + c4;
     if (P.self_loop) {
-        const float4 h = ld4(feat + (size_t)row * P.ld_feat);
+        const float4 h = ld4(feat_self + (size_t)row * P.ld_self);
         if (MODE == AGG_GAT) {
             const int F4 = P.F / 4, pos = sl % F4;
             const bool pow2 = (F4 & (F4 - 1)) == 0;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
             const float a = head_sum(dot4(h, ld4(P.att_src + c4)), lane, pos, F4, pow2);
             st.push(leaky(a + a_d, P.neg_slope), h);
         } else if (MODE == AGG_GCN) {
-            const float di = P.dinv[row];
+            const float di = P.dinv_self[row];
             sum = fma4(di * di, h, sum);
         }
     }

@@ -76,6 +76,13 @@ struct Relation {
     int n_hub = 0, n_slots = 0;
     int64_t rows_owned = 0, edges_owned = 0;
     int64_t edges_short = 0, edges_long = 0;  // owned edges by kernel (short rows / long items + hub chunks)
+    // multi-GPU (set by pea_plan_set_sources): source ids renamed to slots of the exchange buffer [world*M rows]
+    int *col_slot = nullptr;
+    int64_t slots_per_rank = 0;                        // M
+    float *dinv_row_slot = nullptr, *dinv_col_slot = nullptr;  // GCN deg^-1/2 in slot order (lazy)
+    int *slot_of_node = nullptr;                       // device [N], -1 = not a source
+    int *need_rows = nullptr;                          // device: rows whose level-0 transform this rank computes
+    int64_t n_need = 0;
 };
 
 }  // namespace pea
@@ -86,11 +93,14 @@ struct pea_plan {
     int shard_rank = 0, shard_world = 1, shard_tile = 256;
     std::vector<pea::Relation> rels;
     int max_slots = 0;  // max hub chunks over relations (sizes the partial workspace)
+    int *owned_rows = nullptr;  // device, sharded plans only
+    int64_t n_owned = 0;
 };
 
 namespace pea {
 
 int ensure_dinv(pea_plan *plan, int rel, bool from_col, hipStream_t stream);
+int ensure_dinv_slots(pea_plan *plan, int rel, bool from_col, hipStream_t stream);
 
 // ---------------------------------------------------------------- aggregation (agg.hip)
 enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2 };
@@ -103,14 +113,16 @@ struct AggGroup {
     const LongItem *long_items;
     const int *hub_rows, *hub_first, *hub_count;
     int n_short, n_long, n_hub;
-    const float *feat;   // gather source; row j at feat + j*ld_feat
+    const float *feat;   // gather source; row col[e] at feat + col[e]*ld_feat (node ids, or exchange slots when sharded)
+    const float *feat_self;  // the destination node's own row (self loop, a_dst), indexed by node id, stride ld_self
     const float *att_src;  // GAT: att_j flattened over the group's columns [W] (multiplies the SOURCE row)
     const float *att_dst;  // GAT: att_i flattened [W] (multiplies the TARGET row)
-    const float *dinv;   // GCN
+    const float *dinv;   // GCN deg^-1/2 indexed like `col`
+    const float *dinv_self;  // GCN deg^-1/2 indexed by node id
     const float *bias;   // [W] or null
     float *out;          // row i at out + i*ld_out
     float *partial;      // hub partial records
-    int ld_feat, ld_out;
+    int ld_feat, ld_self, ld_out;
     int W;               // columns of this group (multiple of 4, <= 256)
     int F;               // columns per attention group (GAT), W % F == 0
     int relu;
@@ -172,7 +184,7 @@ int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const C
                 const float *att, int masked, int mode, const int *rows, int64_t n_rows, float *out,
                 float *out_stack, hipStream_t stream);
 
-int model_forward(pea_model *m, const float *const *params, const float *x, int64_t ldx, const float *att,
+int model_forward(pea_model *m, int stage, const float *const *params, const float *x, int64_t ldx, const float *att,
                   int masked, float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x,
                   int relu_last, hipStream_t stream);
 

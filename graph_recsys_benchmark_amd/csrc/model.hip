@@ -44,6 +44,8 @@ struct GroupPlan {  // one aggregation group of a level
     size_t bias_off = 0;        // packed bias (floats from the pack base), GAT/GCN
     size_t partial_off = 0;     // floats from the partial base
     int n_convs = 1;            // reference conv calls this group serves (index reads it saves)
+    size_t xch_off = 0;         // sharded, level >= 1: exchange buffer [world*M rows, xch_ld] (floats from the workspace base)
+    int xch_ld = 0;
 };
 
 struct Level {
@@ -109,7 +111,7 @@ int build_schedule(pea_model *m) {
     m->levels.assign((size_t)Smax, Level());
     std::vector<int> in_w((size_t)P, d.emb_dim), in_col((size_t)P, 0);
     int x_cols = 0;
-    size_t pack = 0, ws = 0, partial_max = 0;
+    size_t pack = 0, ws = 0, partial_max = 0, xch = 0;
     m->messages = 0;
     m->alg_bytes = 0.0;
 
@@ -279,6 +281,13 @@ int build_schedule(pea_model *m) {
             }
         }
         partial_max = std::max(partial_max, partial);
+        if (plan->shard_world > 1 && s > 0) {
+            for (GroupPlan &g : L.groups) {
+                g.xch_ld = pad_ld(g.W);
+                g.xch_off = xch;  // relative; rebased below
+                xch = pad_off(xch + (size_t)plan->shard_world * (size_t)plan->rels[(size_t)g.rel].slots_per_rank * (size_t)g.xch_ld);
+            }
+        }
         L.off_t = ws;
         ws = pad_off(ws + (size_t)N * (size_t)L.ld_t);
         L.off_a = ws;
@@ -312,8 +321,12 @@ int build_schedule(pea_model *m) {
     m->off_x = off;
     off = pad_off(off + (size_t)N * (size_t)m->ld_x);
     m->off_partial = off;
-    m->partial_floats = (partial_max + 3) & ~(size_t)3;
+    m->partial_floats = pad_off(partial_max);
     off += m->partial_floats;
+    for (Level &L : m->levels)
+        for (GroupPlan &g : L.groups)
+            if (g.xch_ld) g.xch_off += off;
+    off += xch;
     m->total_floats = off;
     return PEA_OK;
 }
@@ -348,8 +361,8 @@ int init_model(pea_model *m, const pea_plan *plan, const pea_model_desc *desc) {
 // params: [sum steps][slots] device pointers, channel-major.  ldx: row stride of x.
 // out_x / ld_out_x: when non-null the last-layer outputs go there instead of the workspace X (single-conv
 // entry points); relu_last applies relu to last layers too.
-int model_forward(pea_model *m, const float *const *params, const float *x, int64_t ldx, const float *att, int masked,
-                  float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x, int relu_last,
+int model_forward(pea_model *m, int stage, const float *const *params, const float *x, int64_t ldx, const float *att,
+                  int masked, float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x, int relu_last,
                   hipStream_t stream) {
     const pea_model_desc &d = m->d;
     pea_plan *plan = const_cast<pea_plan *>(m->plan);
@@ -364,118 +377,153 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
         return params[(size_t)(m->chan_first[(size_t)u.p] + u.s) * (size_t)slots + (size_t)slot];
     };
 
-    // ---- 1. pack weights (they change every optimizer step) ----
+    const bool sharded = plan->shard_world > 1;
+    const int n_levels = (int)m->levels.size();
+    if (sharded) PEA_REQUIRE(plan->owned_rows != nullptr || plan->n_owned == 0, PEA_ERR_ARG, "sharded plan without owned rows");
+    const int *own_rows = sharded ? plan->owned_rows : nullptr;
+    const int64_t n_own = sharded ? plan->n_owned : N;
+
+    // ---- pack weights (they change every optimizer step) ----
+    auto pack_weights = [&]() -> int {
     std::vector<PackJob> pj;
-    for (Level &L : m->levels) {
-        for (size_t ui = 0; ui < L.units.size(); ++ui) {
-            const Unit &u = L.units[ui];
-            PackJob j{};
-            j.kind = kind;
-            j.B = pack + u.b_off;
-            j.ldb = u.ldb;
-            j.in = u.in_w;
-            j.HF = u.HF;
-            j.F = u.F;
-            j.bias = pack + u.bias_off;
-            j.w0 = param(u, 0);
-            PEA_REQUIRE(j.w0 != nullptr, PEA_ERR_ARG, "forward: null weight pointer (channel %d step %d)", u.p, u.s);
-            if (kind == PEA_KIND_GAT) {
-                j.w1 = param(u, 1);
-                j.w2 = param(u, 2);
-                j.w3 = param(u, 3);
-                PEA_REQUIRE(j.w1 && j.w2, PEA_ERR_ARG, "forward: null att_i/att_j (channel %d step %d)", u.p, u.s);
-                j.att_src = pack + L.att_src_off + u.t_col;
-                j.att_dst = pack + L.att_dst_off + u.t_col;
-            } else if (kind == PEA_KIND_GCN) {
-                j.w3 = param(u, 1);
-            } else {
-                j.w3 = param(u, 1);
-                j.w1 = param(u, 2);
-                PEA_REQUIRE(j.w1 != nullptr, PEA_ERR_ARG, "forward: null lin_root.weight (channel %d step %d)", u.p, u.s);
-            }
-            if (L.shared_input) {  // the last unit clears the block's padding columns
-                if (ui + 1 == L.units.size()) {
-                    const int used = L.n_cols;
-                    j.zero_col = used - u.t_col;
-                    j.zero_n = L.n_out - used;
-                }
-            } else {
-                const int used = u.HF;
-                j.zero_col = used;
-                j.zero_n = u.ldb - used;
-            }
-            pj.push_back(j);
-        }
-    }
-    PEA_TRY(launch_pack(pj.data(), (int)pj.size(), stream));
-
-    // ---- 2. levels ----
-    for (size_t s = 0; s < m->levels.size(); ++s) {
-        Level &L = m->levels[s];
-        float *T = wsf + L.off_t, *O = wsf + L.off_o;
-        const float *In = s == 0 ? x : wsf + m->levels[s - 1].off_o;
-        const int64_t ldIn = s == 0 ? ldx : m->levels[s - 1].ld_o;
-
-        auto run_groups = [&](AggMode mode) -> int {
-            std::vector<AggGroup> gs;
-            for (const GroupPlan &g : L.groups) {
-                const Relation &R = plan->rels[(size_t)g.rel];
-                AggGroup a{};
-                a.rowptr = R.rowptr;
-                a.col = R.col;
-                a.short_rows = R.short_rows;
-                a.long_items = R.long_items;
-                a.hub_rows = R.hub_rows;
-                a.hub_first = R.hub_first;
-                a.hub_count = R.hub_count;
-                a.n_short = R.n_short;
-                a.n_long = R.n_long;
-                a.n_hub = R.n_hub;
-                a.W = g.W;
-                a.F = g.F;
-                a.partial = partial + g.partial_off;
-                a.neg_slope = d.negative_slope;
-                {
-                    const double loops = (mode != AGG_MEAN && (plan->flags & PEA_PLAN_SELF_LOOPS)) ? 1.0 : 0.0;
-                    a.msgs_short = (double)R.edges_short + loops * R.n_short;
-                    a.msgs_long = (double)R.edges_long + loops * (R.n_long - R.n_slots);
-                    a.idx_share = mode == AGG_MEAN ? 1.0 : (double)g.n_convs;
-                }
-                if (mode == AGG_MEAN) {
-                    a.feat = In + g.col;
-                    a.ld_feat = (int)ldIn;
-                    a.out = T + g.out_col;
-                    a.ld_out = L.ld_t;
+        for (Level &L : m->levels) {
+            for (size_t ui = 0; ui < L.units.size(); ++ui) {
+                const Unit &u = L.units[ui];
+                PackJob j{};
+                j.kind = kind;
+                j.B = pack + u.b_off;
+                j.ldb = u.ldb;
+                j.in = u.in_w;
+                j.HF = u.HF;
+                j.F = u.F;
+                j.bias = pack + u.bias_off;
+                j.w0 = param(u, 0);
+                PEA_REQUIRE(j.w0 != nullptr, PEA_ERR_ARG, "forward: null weight pointer (channel %d step %d)", u.p, u.s);
+                if (kind == PEA_KIND_GAT) {
+                    j.w1 = param(u, 1);
+                    j.w2 = param(u, 2);
+                    j.w3 = param(u, 3);
+                    PEA_REQUIRE(j.w1 && j.w2, PEA_ERR_ARG, "forward: null att_i/att_j (channel %d step %d)", u.p, u.s);
+                    j.att_src = pack + L.att_src_off + u.t_col;
+                    j.att_dst = pack + L.att_dst_off + u.t_col;
+                } else if (kind == PEA_KIND_GCN) {
+                    j.w3 = param(u, 1);
                 } else {
-                    a.feat = T + g.col;
-                    a.ld_feat = L.ld_t;
-                    a.att_src = pack + L.att_src_off + g.col;
-                    a.att_dst = pack + L.att_dst_off + g.col;
-                    a.bias = pack + g.bias_off;
-                    a.self_loop = (plan->flags & PEA_PLAN_SELF_LOOPS) ? 1 : 0;
-                    if (g.last) {
-                        a.out = X + g.out_col;
-                        a.ld_out = (int)ldX;
-                        a.relu = relu_last;
-                    } else {
-                        a.out = O + g.out_col;
-                        a.ld_out = L.ld_o;
-                        a.relu = 1;
+                    j.w3 = param(u, 1);
+                    j.w1 = param(u, 2);
+                    PEA_REQUIRE(j.w1 != nullptr, PEA_ERR_ARG, "forward: null lin_root.weight (channel %d step %d)", u.p, u.s);
+                }
+                if (L.shared_input) {  // the last unit clears the block's padding columns
+                    if (ui + 1 == L.units.size()) {
+                        const int used = L.n_cols;
+                        j.zero_col = used - u.t_col;
+                        j.zero_n = L.n_out - used;
                     }
-                    if (mode == AGG_GCN) {
-                        PEA_TRY(ensure_dinv(plan, g.rel, d.gcn_deg_from_col != 0, stream));
-                        a.dinv = d.gcn_deg_from_col ? R.dinv_col : R.dinv_row;
+                } else {
+                    const int used = u.HF;
+                    j.zero_col = used;
+                    j.zero_n = u.ldb - used;
+                }
+                pj.push_back(j);
+            }
+        }
+        PEA_TRY(launch_pack(pj.data(), (int)pj.size(), stream));
+
+        return PEA_OK;
+    };
+
+    auto level_io = [&](int s, float *&T, float *&O, const float *&In, int64_t &ldIn) {
+        Level &L = m->levels[(size_t)s];
+        T = wsf + L.off_t;
+        O = wsf + L.off_o;
+        In = s == 0 ? x : wsf + m->levels[(size_t)s - 1].off_o;
+        ldIn = s == 0 ? ldx : m->levels[(size_t)s - 1].ld_o;
+    };
+
+    // neighbour aggregation of level s
+    auto run_groups = [&](int s, AggMode mode) -> int {
+        Level &L = m->levels[(size_t)s];
+        float *T, *O;
+        const float *In;
+        int64_t ldIn;
+        level_io(s, T, O, In, ldIn);
+        std::vector<AggGroup> gs;
+        for (const GroupPlan &g : L.groups) {
+            Relation &R = plan->rels[(size_t)g.rel];
+            const bool via_slots = sharded && s > 0;  // gather sources arrive through the exchange buffer
+            if (via_slots) PEA_REQUIRE(R.col_slot != nullptr, PEA_ERR_ARG, "relation %d has no exchange layout (pea_plan_set_sources)", g.rel);
+            AggGroup a{};
+            a.rowptr = R.rowptr;
+            a.col = via_slots ? R.col_slot : R.col;
+            a.short_rows = R.short_rows;
+            a.long_items = R.long_items;
+            a.hub_rows = R.hub_rows;
+            a.hub_first = R.hub_first;
+            a.hub_count = R.hub_count;
+            a.n_short = R.n_short;
+            a.n_long = R.n_long;
+            a.n_hub = R.n_hub;
+            a.W = g.W;
+            a.F = g.F;
+            a.partial = partial + g.partial_off;
+            a.neg_slope = d.negative_slope;
+            {
+                const double loops = (mode != AGG_MEAN && (plan->flags & PEA_PLAN_SELF_LOOPS)) ? 1.0 : 0.0;
+                a.msgs_short = (double)R.edges_short + loops * R.n_short;
+                a.msgs_long = (double)R.edges_long + loops * (R.n_long - R.n_slots);
+                a.idx_share = mode == AGG_MEAN ? 1.0 : (double)g.n_convs;
+            }
+            if (mode == AGG_MEAN) {
+                a.feat = via_slots ? wsf + g.xch_off : In + g.col;
+                a.ld_feat = via_slots ? g.xch_ld : (int)ldIn;
+                a.feat_self = In + g.col;  // unused (no self loop)
+                a.ld_self = (int)ldIn;
+                a.out = T + g.out_col;
+                a.ld_out = L.ld_t;
+            } else {
+                a.feat = via_slots ? wsf + g.xch_off : T + g.col;
+                a.ld_feat = via_slots ? g.xch_ld : L.ld_t;
+                a.feat_self = T + g.col;
+                a.ld_self = L.ld_t;
+                a.att_src = pack + L.att_src_off + g.col;
+                a.att_dst = pack + L.att_dst_off + g.col;
+                a.bias = pack + g.bias_off;
+                a.self_loop = (plan->flags & PEA_PLAN_SELF_LOOPS) ? 1 : 0;
+                if (g.last) {
+                    a.out = X + g.out_col;
+                    a.ld_out = (int)ldX;
+                    a.relu = relu_last;
+                } else {
+                    a.out = O + g.out_col;
+                    a.ld_out = L.ld_o;
+                    a.relu = 1;
+                }
+                if (mode == AGG_GCN) {
+                    const bool fc = d.gcn_deg_from_col != 0;
+                    PEA_TRY(ensure_dinv(plan, g.rel, fc, stream));
+                    a.dinv_self = fc ? R.dinv_col : R.dinv_row;
+                    a.dinv = a.dinv_self;
+                    if (via_slots) {
+                        PEA_TRY(ensure_dinv_slots(plan, g.rel, fc, stream));
+                        a.dinv = fc ? R.dinv_col_slot : R.dinv_row_slot;
                     }
                 }
-                gs.push_back(a);
             }
-            for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
-                PEA_TRY(launch_aggregate(mode, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
-            return PEA_OK;
-        };
+            gs.push_back(a);
+        }
+        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+            PEA_TRY(launch_aggregate(mode, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        return PEA_OK;
+    };
 
+    // dense transform of level s (GAT/GCN: before the aggregation; SAGE: after it)
+    auto run_gemm = [&](int s) -> int {
+        Level &L = m->levels[(size_t)s];
+        float *T, *O;
+        const float *In;
+        int64_t ldIn;
+        level_io(s, T, O, In, ldIn);
         if (kind == PEA_KIND_SAGE) {
-            PEA_TRY(run_groups(AGG_MEAN));
             std::vector<GemmJob> jobs;
             for (const Unit &u : L.units) {
                 GemmJob J{};
@@ -503,49 +551,88 @@ int model_forward(pea_model *m, const float *const *params, const float *x, int6
                 }
                 jobs.push_back(J);
             }
-            PEA_TRY(launch_gemm_batch(jobs.data(), (int)jobs.size(), nullptr, N, stream));
-        } else {
-            if (L.shared_input) {
+            return launch_gemm_batch(jobs.data(), (int)jobs.size(), own_rows, n_own, stream);
+        }
+        if (L.shared_input && !sharded) {
+            GemmJob J{};
+            J.A1 = In;
+            J.lda1 = (int)ldIn;
+            J.K1 = d.emb_dim;
+            J.B = pack + L.b_off;
+            J.ldb = L.ldb;
+            J.n_out = L.n_out;
+            J.n_seg = 1;
+            J.seg[0].c0 = 0;
+            J.seg[0].c1 = L.n_cols;
+            J.seg[0].dst = T;
+            J.seg[0].ld = L.ld_t;
+            return launch_gemm(J, nullptr, N, stream);
+        }
+        if (L.shared_input) {
+            // sharded level 0: x is replicated, so each rank transforms, per relation, exactly the rows it will
+            // read: its own rows plus that relation's source nodes (plan need_rows)
+            size_t i = 0;
+            while (i < L.units.size()) {
+                size_t j = i;
+                while (j < L.units.size() && L.units[j].rel == L.units[i].rel) ++j;
+                const Relation &R = plan->rels[(size_t)L.units[i].rel];
+                PEA_REQUIRE(R.need_rows != nullptr || R.n_need == 0, PEA_ERR_ARG, "relation %d has no need_rows (pea_plan_set_sources)", L.units[i].rel);
+                const int c_beg = L.units[i].t_col, c_end = L.units[j - 1].t_col + L.units[j - 1].HF;
                 GemmJob J{};
                 J.A1 = In;
                 J.lda1 = (int)ldIn;
                 J.K1 = d.emb_dim;
-                J.B = pack + L.b_off;
+                J.B = pack + L.b_off + c_beg;
                 J.ldb = L.ldb;
-                J.n_out = L.n_out;
+                J.n_out = c_end - c_beg;
                 J.n_seg = 1;
                 J.seg[0].c0 = 0;
-                J.seg[0].c1 = L.n_cols;
-                J.seg[0].dst = T;
+                J.seg[0].c1 = c_end - c_beg;
+                J.seg[0].dst = T + c_beg;
                 J.seg[0].ld = L.ld_t;
-                PEA_TRY(launch_gemm(J, nullptr, N, stream));
-            } else {
-                std::vector<GemmJob> jobs;
-                for (const Unit &u : L.units) {
-                    GemmJob J{};
-                    J.A1 = In + u.in_col;
-                    J.lda1 = (int)ldIn;
-                    J.K1 = u.in_w;
-                    J.B = pack + u.b_off;
-                    J.ldb = u.ldb;
-                    J.n_out = u.ldb;
-                    J.n_seg = 1;
-                    J.seg[0].c0 = 0;
-                    J.seg[0].c1 = u.HF;
-                    J.seg[0].dst = T + u.t_col;
-                    J.seg[0].ld = L.ld_t;
-                    jobs.push_back(J);
-                }
-                PEA_TRY(launch_gemm_batch(jobs.data(), (int)jobs.size(), nullptr, N, stream));
+                PEA_TRY(launch_gemm(J, R.need_rows, R.n_need, stream));
+                i = j;
             }
-            PEA_TRY(run_groups(kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
+            return PEA_OK;
         }
-    }
+        std::vector<GemmJob> jobs;
+        for (const Unit &u : L.units) {
+            GemmJob J{};
+            J.A1 = In + u.in_col;
+            J.lda1 = (int)ldIn;
+            J.K1 = u.in_w;
+            J.B = pack + u.b_off;
+            J.ldb = u.ldb;
+            J.n_out = u.ldb;
+            J.n_seg = 1;
+            J.seg[0].c0 = 0;
+            J.seg[0].c1 = u.HF;
+            J.seg[0].dst = T + u.t_col;
+            J.seg[0].ld = L.ld_t;
+            jobs.push_back(J);
+        }
+        return launch_gemm_batch(jobs.data(), (int)jobs.size(), own_rows, n_own, stream);
+    };
 
-    // ---- 3. fusion ----
-    if (out_repr || out_stack)
-        PEA_TRY(launch_fuse(N, d.num_channels, d.repr_dim, X, ldX, m->x_col, att, masked, d.fuse_mode, nullptr, N, out_repr,
-                            out_stack, stream));
+    // Stage k = the work between two exchanges of gather sources (all stages back to back when not sharded):
+    //   GAT/GCN: [k == 0: pack, transform_0]  aggregate_k  [transform_{k+1}]        SAGE: [pack]  aggregate_k  transform_k
+    // After stage k < last, the gather source of level k+1 is complete on its owner rows (T_{k+1} resp. O_k).
+    const int s_beg = stage < 0 ? 0 : stage, s_end = stage < 0 ? n_levels : stage + 1;
+    PEA_REQUIRE(s_beg >= 0 && s_end <= n_levels, PEA_ERR_ARG, "forward: stage %d of %d", stage, n_levels);
+    for (int k = s_beg; k < s_end; ++k) {
+        if (k == 0) PEA_TRY(pack_weights());
+        if (kind == PEA_KIND_SAGE) {
+            PEA_TRY(run_groups(k, AGG_MEAN));
+            PEA_TRY(run_gemm(k));
+        } else {
+            if (k == 0) PEA_TRY(run_gemm(0));
+            PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
+            if (k + 1 < n_levels) PEA_TRY(run_gemm(k + 1));
+        }
+        if (k == n_levels - 1 && (out_repr || out_stack))
+            PEA_TRY(launch_fuse(N, d.num_channels, d.repr_dim, X, ldX, m->x_col, att, masked, d.fuse_mode, own_rows, n_own,
+                                out_repr, out_stack, stream));
+    }
     return PEA_OK;
 }
 
@@ -598,8 +685,44 @@ extern "C" int pea_model_forward(pea_model *model, const float *const *params_ho
     PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward: masked channel %d", masked_channel);
     PEA_REQUIRE(out_repr || out_stack, PEA_ERR_ARG, "forward: no output requested");
     PEA_REQUIRE(model->d.fuse_mode == PEA_FUSE_MEAN || att || !out_repr, PEA_ERR_ARG, "forward: att is required for 'att' fusion");
-    return model_forward(model, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr, out_stack,
-                         nullptr, 0, 0, (hipStream_t)stream);
+    return model_forward(model, -1, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
+                         out_stack, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int pea_model_num_stages(const pea_model *model) { return model ? (int)model->levels.size() : 0; }
+
+extern "C" int pea_model_forward_stage(pea_model *model, int stage, const float *const *params_host, const float *x,
+                                       const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
+                                       float *out_repr, float *out_stack, void *stream) {
+    PEA_REQUIRE(model && params_host && x && workspace, PEA_ERR_ARG, "forward_stage: null argument");
+    PEA_REQUIRE(stage >= 0 && stage < (int)model->levels.size(), PEA_ERR_ARG, "forward_stage: stage %d of %d", stage,
+                (int)model->levels.size());
+    PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(model), PEA_ERR_NOMEM, "forward_stage: workspace too small");
+    PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward_stage: masked channel %d", masked_channel);
+    return model_forward(model, stage, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
+                         out_stack, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int pea_model_num_exchanges(const pea_model *model, int level) {
+    if (!model || level < 1 || level >= (int)model->levels.size() || model->plan->shard_world <= 1) return 0;
+    return (int)model->levels[(size_t)level].groups.size();
+}
+
+extern "C" int pea_model_exchange_desc(const pea_model *model, int level, int k, pea_exchange_desc *out) {
+    PEA_REQUIRE(model && out && k >= 0 && k < pea_model_num_exchanges(model, level), PEA_ERR_ARG, "exchange_desc: bad argument");
+    const Level &L = model->levels[(size_t)level];
+    const GroupPlan &g = L.groups[(size_t)k];
+    const bool sage = model->d.kind == PEA_KIND_SAGE;
+    out->relation = g.rel;
+    out->slots_per_rank = model->plan->rels[(size_t)g.rel].slots_per_rank;
+    out->width = g.W;
+    out->dst_ld = g.xch_ld;
+    out->dst_offset_bytes = g.xch_off * sizeof(float);
+    // the gather source of level `level`: T_level (GAT/GCN) or O_{level-1} (SAGE), columns [src_col, src_col + width)
+    out->src_offset_bytes = (sage ? model->levels[(size_t)level - 1].off_o : L.off_t) * sizeof(float);
+    out->src_ld = sage ? model->levels[(size_t)level - 1].ld_o : L.ld_t;
+    out->src_col = g.col;
+    return PEA_OK;
 }
 
 // ---- single conv layers: a one-channel, one-step schedule built on the host per call ----
@@ -631,7 +754,7 @@ static int single_conv(int kind, const pea_plan *plan, int relation, int in_chan
     PEA_REQUIRE(ldx >= in_channels && ldx % 4 == 0 && ldo >= (int64_t)heads * out_channels && ldo % 4 == 0, PEA_ERR_ARG,
                 "conv: row strides (%lld, %lld) must be multiples of 4 covering the row", (long long)ldx, (long long)ldo);
     PEA_REQUIRE(workspace_bytes >= m.total_floats * sizeof(float) + 256, PEA_ERR_NOMEM, "conv: workspace too small");
-    return model_forward(&m, params, x, ldx, nullptr, -1, aligned_ws(workspace), nullptr, nullptr, out, ldo, relu,
+    return model_forward(&m, -1, params, x, ldx, nullptr, -1, aligned_ws(workspace), nullptr, nullptr, out, ldo, relu,
                          (hipStream_t)stream);
 }
 

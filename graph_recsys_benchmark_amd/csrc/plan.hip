@@ -172,7 +172,26 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     return PEA_OK;
 }
 
+__global__ void rename_sources(int64_t E, const int *__restrict__ col, const int *__restrict__ slot_of_node,
+                               int *__restrict__ col_slot, int *err) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int s = slot_of_node[col[e]];
+    if (s < 0) atomicOr(err, 1);
+    col_slot[e] = s < 0 ? 0 : s;
+}
+
+__global__ void scatter_to_slots(int64_t N, const int *__restrict__ slot_of_node, const float *__restrict__ src,
+                                 float *__restrict__ dst) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int s = slot_of_node[v];
+    if (s >= 0) dst[s] = src[v];
+}
+
 void free_relation(Relation &R) {
+    (void)hipFree(R.col_slot); (void)hipFree(R.dinv_row_slot); (void)hipFree(R.dinv_col_slot);
+    (void)hipFree(R.slot_of_node); (void)hipFree(R.need_rows);
     (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col);
     (void)hipFree(R.short_rows); (void)hipFree(R.long_items);
     (void)hipFree(R.hub_rows); (void)hipFree(R.hub_first); (void)hipFree(R.hub_count);
@@ -202,7 +221,73 @@ int ensure_dinv(pea_plan *plan, int rel, bool from_col, hipStream_t stream) {
     return PEA_OK;
 }
 
+int ensure_dinv_slots(pea_plan *plan, int rel, bool from_col, hipStream_t stream) {
+    PEA_TRY(ensure_dinv(plan, rel, from_col, stream));
+    Relation &R = plan->rels[(size_t)rel];
+    float **slot = from_col ? &R.dinv_col_slot : &R.dinv_row_slot;
+    if (*slot) return PEA_OK;
+    PEA_REQUIRE(R.slot_of_node != nullptr, PEA_ERR_ARG, "relation %d has no exchange layout (pea_plan_set_sources)", rel);
+    const size_t n = (size_t)std::max<int64_t>(R.slots_per_rank * plan->shard_world, 1);
+    PEA_HIP(hipMalloc((void **)slot, n * sizeof(float)));
+    PEA_HIP(hipMemsetAsync(*slot, 0, n * sizeof(float), stream));
+    hipLaunchKernelGGL(scatter_to_slots, dim3((unsigned)((plan->N + 255) / 256)), dim3(256), 0, stream, plan->N,
+                       R.slot_of_node, from_col ? R.dinv_col : R.dinv_row, *slot);
+    PEA_HIP(hipGetLastError());
+    PEA_HIP(hipStreamSynchronize(stream));
+    return PEA_OK;
+}
+
 }  // namespace pea
+
+extern "C" int pea_plan_set_owned_rows(pea_plan *plan, const int32_t *rows, int64_t n, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PEA_REQUIRE(plan && n >= 0 && (n == 0 || rows), PEA_ERR_ARG, "set_owned_rows: bad argument");
+    (void)hipFree(plan->owned_rows);
+    plan->owned_rows = nullptr;
+    plan->n_owned = n;
+    if (n > 0) {
+        PEA_HIP(hipMalloc((void **)&plan->owned_rows, (size_t)n * sizeof(int)));
+        PEA_HIP(hipMemcpyAsync(plan->owned_rows, rows, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, stream));
+        PEA_HIP(hipStreamSynchronize(stream));
+    }
+    return PEA_OK;
+}
+
+extern "C" int pea_plan_set_sources(pea_plan *plan, int relation, const int32_t *slot_of_node, int64_t slots_per_rank,
+                                    const int32_t *need_rows, int64_t n_need, void *stream_) {
+    using namespace pea;
+    hipStream_t stream = (hipStream_t)stream_;
+    PEA_REQUIRE(plan && relation >= 0 && relation < (int)plan->rels.size() && slot_of_node && slots_per_rank >= 0 &&
+                    n_need >= 0 && (n_need == 0 || need_rows), PEA_ERR_ARG, "set_sources: bad argument");
+    PEA_REQUIRE(slots_per_rank * plan->shard_world < (int64_t)INT32_MAX, PEA_ERR_ARG, "set_sources: too many slots");
+    Relation &R = plan->rels[(size_t)relation];
+    (void)hipFree(R.col_slot); (void)hipFree(R.slot_of_node); (void)hipFree(R.need_rows);
+    (void)hipFree(R.dinv_row_slot); (void)hipFree(R.dinv_col_slot);
+    R.col_slot = R.slot_of_node = R.need_rows = nullptr;
+    R.dinv_row_slot = R.dinv_col_slot = nullptr;
+    R.slots_per_rank = slots_per_rank;
+    R.n_need = n_need;
+    PEA_HIP(hipMalloc((void **)&R.slot_of_node, (size_t)plan->N * sizeof(int)));
+    PEA_HIP(hipMemcpyAsync(R.slot_of_node, slot_of_node, (size_t)plan->N * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    if (n_need > 0) {
+        PEA_HIP(hipMalloc((void **)&R.need_rows, (size_t)n_need * sizeof(int)));
+        PEA_HIP(hipMemcpyAsync(R.need_rows, need_rows, (size_t)n_need * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    }
+    PEA_HIP(hipMalloc((void **)&R.col_slot, (size_t)std::max<int64_t>(R.e_kept, 1) * sizeof(int)));
+    int *err = nullptr, herr = 0;
+    PEA_HIP(hipMalloc((void **)&err, sizeof(int)));
+    PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
+    if (R.e_kept > 0)
+        hipLaunchKernelGGL(rename_sources, dim3((unsigned)((R.e_kept + 255) / 256)), dim3(256), 0, stream, R.e_kept, R.col,
+                           R.slot_of_node, R.col_slot, err);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(err);
+    PEA_REQUIRE(e == hipSuccess, PEA_ERR_HIP, "set_sources: %s", hipGetErrorString(e));
+    PEA_REQUIRE(herr == 0, PEA_ERR_ARG, "set_sources: a source node of relation %d has no slot", relation);
+    return PEA_OK;
+}
 
 extern "C" int pea_plan_create(int64_t num_nodes, int n_relations, const int64_t *const *coo_host,
                                const int64_t *num_edges_host, int flags, int shard_rank, int shard_world,
@@ -239,6 +324,7 @@ extern "C" int pea_plan_create(int64_t num_nodes, int n_relations, const int64_t
 extern "C" int pea_plan_destroy(pea_plan *plan) {
     if (!plan) return PEA_OK;
     for (auto &R : plan->rels) pea::free_relation(R);
+    (void)hipFree(plan->owned_rows);
     delete plan;
     return PEA_OK;
 }

@@ -11,6 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .sharding import ShardLayout
 
 KINDS = {'gat': _lib.KIND_GAT, 'gcn': _lib.KIND_GCN, 'sage': _lib.KIND_SAGE}
 # parameter slots per conv layer, in the order pea_model_forward expects (include/peahip.h)
@@ -74,6 +75,17 @@ class GraphPlan:
                                        self.shard[2], _lib.current_stream(), C.byref(handle)))
         self._h = handle
         self.device = uniq[0].device
+        self.layout = ShardLayout(self.num_nodes, *self.shard)
+        self.source_layouts = {}
+        if self.shard[1] > 1:
+            own = self.layout.owned_rows(self.device).to(torch.int32).contiguous()
+            _lib.check(lib.pea_plan_set_owned_rows(handle, _lib.ptr(own), own.numel(), _lib.current_stream()))
+            for r, ei in enumerate(uniq):
+                lay = self.layout.source_layout(ei)
+                need = lay.need_rows.contiguous()
+                _lib.check(lib.pea_plan_set_sources(handle, r, _lib.ptr(lay.slot_of_node.contiguous()), lay.slots_per_rank,
+                                                    _lib.ptr(need), need.numel(), _lib.current_stream()))
+                self.source_layouts[r] = lay
 
     def relation_info(self, r):
         info = (C.c_int64 * 8)()
@@ -133,6 +145,24 @@ class PEAEngine:
         msgs, ab = C.c_int64(), C.c_double()
         _lib.check(lib.pea_model_stats(handle, C.byref(msgs), C.byref(ab)))
         self.messages, self.algorithmic_bytes = int(msgs.value), float(ab.value)
+        self.sharded = plan.shard[1] > 1
+        self.n_stages = int(lib.pea_model_num_stages(handle))
+        # float32 view of the workspace from its 256-byte aligned base (the exchanges index into it)
+        skew = (-self._ws.data_ptr()) % 256
+        self._wsf = self._ws[skew:skew + (self.workspace_bytes - 256) // 4 * 4].view(torch.float32)
+        self._exchanges = []            # per level >= 1: [(desc, source table view, exchange buffer view, layout)]
+        if self.sharded:
+            n, world = plan.num_nodes, plan.shard[1]
+            for level in range(self.n_stages):
+                row = []
+                for k in range(int(lib.pea_model_num_exchanges(handle, level))):
+                    d = _lib.ExchangeDesc()
+                    _lib.check(lib.pea_model_exchange_desc(handle, level, k, C.byref(d)))
+                    src = self._wsf[d.src_offset_bytes // 4:d.src_offset_bytes // 4 + n * d.src_ld].view(n, d.src_ld)
+                    rows = world * d.slots_per_rank
+                    dst = self._wsf[d.dst_offset_bytes // 4:d.dst_offset_bytes // 4 + rows * d.dst_ld].view(rows, d.dst_ld)
+                    row.append((d, src, dst, plan.source_layouts[d.relation]))
+                self._exchanges.append(row)
 
     def forward(self, layer_params, x, att=None, masked=None, want_stack=False):
         """layer_params: list (channel-major, then step) of tuples of tensors in PARAM_SLOTS order
@@ -168,9 +198,25 @@ class PEAEngine:
             keep.append(att_t)
         out = torch.empty((n, self.repr_dim), dtype=torch.float32, device=x.device)
         stack = torch.empty((n, self.P, self.repr_dim), dtype=torch.float32, device=x.device) if want_stack else None
-        _lib.check(lib.pea_model_forward(self._h, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t),
-                                         -1 if masked is None else int(masked), _lib.ptr(self._ws),
-                                         self.workspace_bytes, _lib.ptr(out), _lib.ptr(stack), _lib.current_stream()))
+        m = -1 if masked is None else int(masked)
+        if not self.sharded:
+            _lib.check(lib.pea_model_forward(self._h, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m, _lib.ptr(self._ws),
+                                             self.workspace_bytes, _lib.ptr(out), _lib.ptr(stack), _lib.current_stream()))
+            return (out, stack) if want_stack else out
+        # Sharded forward: stage k computes this rank's rows of level k (and the transform feeding level k+1); the
+        # gather sources of level k+1 are then all-gathered from their owners; after the last stage the fused rows
+        # (not the per-metapath stack) are all-gathered: the fusion is row-local under row ownership.
+        shard = self.plan.layout
+        for k in range(self.n_stages):
+            _lib.check(lib.pea_model_forward_stage(self._h, k, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m,
+                                                   _lib.ptr(self._ws), self.workspace_bytes, _lib.ptr(out),
+                                                   _lib.ptr(stack), _lib.current_stream()))
+            if k + 1 < self.n_stages:
+                for d, src, dst, lay in self._exchanges[k + 1]:
+                    shard.exchange_sources(dst, src, lay, d.src_col, d.width)
+        shard.allgather_rows(out)
+        if want_stack:
+            shard.allgather_rows(stack)
         return (out, stack) if want_stack else out
 
     def __del__(self):

@@ -120,6 +120,14 @@ class PEABaseRecsysModel(GraphRecsysModel):
         self.fc2 = torch.nn.Linear(kwargs['repr_dim'], 1)
         self._dims = (kwargs['emb_dim'], kwargs['hidden_size'], kwargs['repr_dim'], kwargs.get('num_heads', 1))
         self._engine = None
+        self._shard = (0, 1, 256)
+
+    def shard(self, rank, world, tile=256):
+        """Multi-GPU: this process computes the destination rows it owns (row i -> rank (i // tile) % world);
+        torch.distributed must be initialised (backend 'nccl' = RCCL on the GPUs)."""
+        self._shard = (int(rank), int(world), int(tile))
+        self._engine = None
+        return self
 
     def reset_parameters(self):
         if not self.if_use_features:
@@ -138,7 +146,8 @@ class PEABaseRecsysModel(GraphRecsysModel):
                 raise NotImplementedError('Other aggr methods not implemeted!')
             emb, hidden, repr_dim, heads = self._dims
             plan = _engine.GraphPlan(self.x.shape[0], self.meta_path_edge_index_list,
-                                     self_loops=self.kind in ('gat', 'gcn'))
+                                     self_loops=self.kind in ('gat', 'gcn'), shard_rank=self._shard[0],
+                                     shard_world=self._shard[1], shard_tile=self._shard[2])
             self._engine = _engine.PEAEngine(plan, self.kind, self.meta_path_steps, emb, hidden, repr_dim,
                                              heads=heads if self.kind == 'gat' else 1,
                                              channel_aggr=self.channel_aggr, gcn_deg_from=self.gcn_deg_from)

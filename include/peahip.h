@@ -121,6 +121,36 @@ int pea_model_params_per_layer(const pea_model *model);
 int pea_model_forward(pea_model *model, const float *const *params_host, const float *x,
                       const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
                       float *out_repr, float *out_stack, void *stream);
+/* ---- multi-GPU (one process per GPU; the library itself never calls RCCL) -------------------------
+ * A sharded plan (shard_world > 1) owns destination rows tile-interleaved.  The host mirror computes the layouts
+ * with torch ops (graph_recsys_benchmark_amd/sharding.py) and hands them over:
+ *   pea_plan_set_owned_rows  rows this rank produces (int32, ascending)
+ *   pea_plan_set_sources     per relation used at a level >= 1: slot_of_node [N] (int32, -1 = not a source;
+ *                            slot = owner_rank * slots_per_rank + index among that owner's sources) -- the source ids
+ *                            of the CSR are renamed to slots of the exchange buffer; and need_rows = the rows whose
+ *                            level-0 transform this rank computes itself (own rows + the relation's sources).
+ * The forward then runs stage by stage; between stage k and k+1 the host fills, for every exchange descriptor of
+ * level k+1, rows [rank*M, rank*M + own) of the exchange buffer from the source buffer and all-gathers it
+ * (ncclAllGather via torch.distributed, in place).  Only owned rows of out_repr / out_stack are written.      */
+typedef struct pea_exchange_desc {
+    int relation;
+    int64_t slots_per_rank;    /* M: rows each rank contributes (padded)                              */
+    int width;                 /* columns exchanged                                                   */
+    int dst_ld;                /* row stride (floats) of the exchange buffer [world*M, dst_ld]        */
+    size_t dst_offset_bytes;   /* exchange buffer, from the 256-byte aligned workspace base           */
+    size_t src_offset_bytes;   /* node-major source buffer [N, src_ld] in the workspace               */
+    int src_ld, src_col;       /* the exchanged columns are [src_col, src_col + width)                */
+} pea_exchange_desc;
+int pea_plan_set_owned_rows(pea_plan *plan, const int32_t *rows, int64_t n, void *stream);
+int pea_plan_set_sources(pea_plan *plan, int relation, const int32_t *slot_of_node, int64_t slots_per_rank,
+                         const int32_t *need_rows, int64_t n_need, void *stream);
+int pea_model_num_stages(const pea_model *model);
+int pea_model_forward_stage(pea_model *model, int stage, const float *const *params_host, const float *x,
+                            const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
+                            float *out_repr, float *out_stack, void *stream);
+int pea_model_num_exchanges(const pea_model *model, int level);
+int pea_model_exchange_desc(const pea_model *model, int level, int k, pea_exchange_desc *out);
+
 /* messages reduced by one forward (sum over channels/steps of kept edges + self loops), and the
  * algorithmic HBM bytes of SURVEY.md section 8(d) for this model -- the roofline yardstick. */
 int pea_model_stats(const pea_model *model, int64_t *messages, double *algorithmic_bytes);

@@ -1,0 +1,96 @@
+"""CPU, world_size 2, gloo: the row-ownership and exchange layouts of the multi-GPU forward
+(graph_recsys_benchmark_amd/sharding.py) -- the same code that runs over RCCL on the GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, tile):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from graph_recsys_benchmark_amd.sharding import ShardLayout
+        from helpers import random_hin
+        from oracle import oracle as orc
+        n, blocks, rel = random_hin(5, n_user=700, n_item=300, n_attr=30, e_u2i=6000, e_attr=500)
+        shard = ShardLayout(n, rank, world, tile)
+        own = shard.owned_rows()
+        # 1. ownership is a partition of the rows
+        gathered = [None] * world
+        dist.all_gather_object(gathered, own.tolist())
+        allrows = sorted(r for part in gathered for r in part)
+        assert allrows == list(range(n))
+        assert all(((r // tile) % world) == rank for r in own.tolist())
+
+        # 2. source exchange: every rank ends with every source row at its slot
+        u2i = torch.from_numpy(rel['u2i'])
+        lay = shard.source_layout(torch.flip(u2i, dims=[0]))          # item -> user: sources are items
+        ms = [None] * world
+        dist.all_gather_object(ms, (lay.slots_per_rank, lay.counts, lay.src_nodes.tolist()))
+        assert all(m == ms[0] for m in ms)                            # layout is global
+        assert sum(lay.counts) == lay.src_nodes.numel() and lay.own_count == lay.counts[rank]
+        truth = torch.arange(n, dtype=torch.float32)[:, None] * 10 + torch.arange(12, dtype=torch.float32)[None, :]
+        local = torch.full_like(truth, float('nan'))
+        local[own] = truth[own]                                       # a rank only ever produces its own rows
+        xbuf = torch.full((world * lay.slots_per_rank, 8), float('nan'))
+        shard.exchange_sources(xbuf, local, lay, col=2, width=6)
+        slots = lay.slot_of_node[lay.src_nodes].long()
+        assert (slots >= 0).all() and slots.unique().numel() == slots.numel()
+        torch.testing.assert_close(xbuf[slots, :6], truth[lay.src_nodes, 2:8], rtol=0, atol=0)
+        assert (lay.slot_of_node[own[~torch.isin(own, lay.src_nodes)]] == -1).all()
+
+        # 3. final all-gather of owned rows
+        table = local.clone()
+        shard.allgather_rows(table)
+        torch.testing.assert_close(table, truth, rtol=0, atol=0)
+
+        # 4. dependency check with the oracle: a rank that knows the conv input only on (owned rows + the
+        #    relation's source nodes) still gets its owned output rows right (NaN-poisoned elsewhere)
+        rng = np.random.default_rng(0)
+        x1 = rng.normal(size=(n, 16)).astype(np.float32)
+        w = rng.normal(size=(8, 16)).astype(np.float32) * 0.3
+        ai = rng.normal(size=(1, 1, 8)).astype(np.float32)
+        aj = rng.normal(size=(1, 1, 8)).astype(np.float32)
+        b = rng.normal(size=(8,)).astype(np.float32) * 0.1
+        ei = np.ascontiguousarray(rel['u2i'][::-1])
+        full = orc.gat_conv(x1, ei, w, ai, aj, b)
+        poisoned = np.full_like(x1, np.nan)
+        need = lay.need_rows.long().numpy()
+        poisoned[need] = x1[need]
+        part = orc.gat_conv(poisoned, ei, w, ai, aj, b)
+        np.testing.assert_array_equal(part[own.numpy()], full[own.numpy()])
+        not_needed = np.setdiff1d(np.arange(n), need)
+        assert not_needed.size > 0 and np.isnan(part[not_needed]).all()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('tile', [64, 256])
+def test_sharding_layouts_world2_gloo(tile):
+    mp.spawn(_worker, args=(2, _free_port(), tile), nprocs=2, join=True)
+
+
+def test_single_rank_is_identity():
+    from graph_recsys_benchmark_amd.sharding import ShardLayout
+    s = ShardLayout(1000, 0, 1)
+    assert s.owned_rows().tolist() == list(range(1000))
+    t = torch.randn(1000, 4)
+    assert s.allgather_rows(t) is t
