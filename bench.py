@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--scale', type=float, default=1.0, help='edge/node count multiplier (tests only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event roofline leg')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' "
+                    'only to rehearse several ranks on one GPU)')
     return ap.parse_args()
 
 
@@ -118,11 +120,15 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     _lib.require_device()
 
     dataset = SyntheticHIN(args.preset, seed=2019, scale=args.scale)

@@ -68,8 +68,9 @@ struct Relation {
     int *col = nullptr;     // device [e_kept] source ids, destination-sorted, stable
     float *dinv_row = nullptr, *dinv_col = nullptr;  // device [N], GCN deg^-1/2 (lazy)
     // work lists (device), restricted to the rows this rank owns
-    int *short_rows = nullptr;
-    int n_short = 0;
+    int *short_rows = nullptr;   // owned rows with <= kShortDeg kept edges; the first n_short0 of them have none
+    int n_short = 0, n_short0 = 0;
+    unsigned char *deg0 = nullptr;  // device [N]: 1 where the row has no kept edge (self loop only)
     LongItem *long_items = nullptr;
     int n_long = 0;
     int *hub_rows = nullptr, *hub_first = nullptr, *hub_count = nullptr;  // per hub row: first slot, #chunks
@@ -146,6 +147,12 @@ struct GemmSegment {   // output columns [c0, c1) of the job go to dst[row*ld + 
 };
 constexpr int kMaxSegments = 4;
 struct GemmJob {
+    // Rows flagged in a1_mask take their A1 block from a1_alt instead, as relu(scale[row] * a1_alt[row] + a1_bias):
+    // a destination row with no incoming edge is exactly  conv(x)_i = h_i (+bias)  (GAT: alpha_ii = 1; GCN:
+    // dinv_i^2 * h_i), so the aggregation skips it and the next layer's transform reads T_s directly.
+    const unsigned char *a1_mask;
+    const float *a1_alt, *a1_bias, *a1_scale;
+    int lda_alt;
     const float *A1;  // [N, K1] row stride lda1
     const float *A2;  // optional second source [N, K2] (SAGE root term), K = K1 + K2
     int lda1, lda2, K1, K2;

@@ -73,6 +73,37 @@ __device__ __forceinline__ float mlp_score(const float *__restrict__ ur, const f
     return o + b2;
 }
 
+// same arithmetic with both rows held in registers (R = 4*R4 known at compile time)
+template <int R4>
+__device__ __forceinline__ float mlp_score_reg(const float4 (&u)[R4], const float4 (&v)[R4], const float *w1, const float *b1,
+                                               const float *w2, float b2) {
+    constexpr int R = 4 * R4;
+    float o = 0.f;
+    for (int k = 0; k < R; ++k) {
+        const float *w = w1 + k * 2 * R;
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < R4; ++c) {
+            const float4 wu = ld4(w + 4 * c);
+            a += (u[c].x * wu.x + u[c].y * wu.y) + (u[c].z * wu.z + u[c].w * wu.w);
+        }
+#pragma unroll
+        for (int c = 0; c < R4; ++c) {
+            const float4 wi = ld4(w + R + 4 * c);
+            a += (v[c].x * wi.x + v[c].y * wi.y) + (v[c].z * wi.z + v[c].w * wi.w);
+        }
+        a += b1[k];
+        o = fmaf(fmaxf(a, 0.f), w2[k], o);
+    }
+    return o + b2;
+}
+
+template <int R4>
+__device__ __forceinline__ void load_row(const float *p, float4 (&r)[R4]) {
+#pragma unroll
+    for (int c = 0; c < R4; ++c) r[c] = ld4(p + 4 * c);
+}
+
 extern __shared__ float smem[];
 
 __device__ __forceinline__ void stage_mlp(int R, const float *fc1_w, const float *fc1_b, const float *fc2_w) {
@@ -104,8 +135,18 @@ __global__ __launch_bounds__(256) void bpr_kernel(int64_t B, int R, int64_t N, c
         if (u < 0 || u >= N || ip < 0 || ip >= N || in < 0 || in >= N) {
             atomicOr(err, 1);
         } else {
-            const float sp = mlp_score(repr + u * R, repr + ip * R, R, w1, b1, w2, fc2_b[0]);
-            const float sn = mlp_score(repr + u * R, repr + in * R, R, w1, b1, w2, fc2_b[0]);
+            float sp, sn;
+            if (R == 16) {  // the reference's repr_dim: all three rows fetched once, up front
+                float4 ur[4], pr[4], nr[4];
+                load_row<4>(repr + u * R, ur);
+                load_row<4>(repr + ip * R, pr);
+                load_row<4>(repr + in * R, nr);
+                sp = mlp_score_reg<4>(ur, pr, w1, b1, w2, fc2_b[0]);
+                sn = mlp_score_reg<4>(ur, nr, w1, b1, w2, fc2_b[0]);
+            } else {
+                sp = mlp_score(repr + u * R, repr + ip * R, R, w1, b1, w2, fc2_b[0]);
+                sn = mlp_score(repr + u * R, repr + in * R, R, w1, b1, w2, fc2_b[0]);
+            }
             if (pos) pos[b] = sp;
             if (neg) neg[b] = sn;
             term = log_sigmoid_ref(sp - sn);

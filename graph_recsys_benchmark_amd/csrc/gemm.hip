@@ -28,11 +28,28 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 template <int KH>
 __device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, int kbase, float (&a)[KH]) {
     const int K = J.K1 + J.K2;
+    const bool alt = J.a1_mask && rv && J.a1_mask[srow];
+    float sc = 1.f;
+    if (alt && J.a1_scale) {
+        const float di = J.a1_scale[srow];
+        sc = di * di;
+    }
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
         const int k = kbase + q * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rv && k < K) v = k < J.K1 ? ld4(J.A1 + srow * J.lda1 + k) : ld4(J.A2 + srow * J.lda2 + (k - J.K1));
+        if (rv && k < K) {
+            if (k >= J.K1) {
+                v = ld4(J.A2 + srow * J.lda2 + (k - J.K1));
+            } else if (alt) {
+                const float4 t = ld4(J.a1_alt + srow * J.lda_alt + k), b = ld4(J.a1_bias + k);
+                // same roundings as the aggregation kernel's finish_row: product, then + bias, then relu
+                v = make_float4(fmaxf(sc * t.x + b.x, 0.f), fmaxf(sc * t.y + b.y, 0.f), fmaxf(sc * t.z + b.z, 0.f),
+                                fmaxf(sc * t.w + b.w, 0.f));
+            } else {
+                v = ld4(J.A1 + srow * J.lda1 + k);
+            }
+        }
         a[q * 4 + 0] = v.x;
         a[q * 4 + 1] = v.y;
         a[q * 4 + 2] = v.z;

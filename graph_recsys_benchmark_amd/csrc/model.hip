@@ -461,6 +461,13 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             a.hub_first = R.hub_first;
             a.hub_count = R.hub_count;
             a.n_short = R.n_short;
+            // rows without incoming edges of a layer that feeds another layer are not aggregated at all: the next
+            // transform reads T_s for them (GemmJob::a1_mask)
+            const bool skip0 = mode != AGG_MEAN && !g.last && (plan->flags & PEA_PLAN_SELF_LOOPS);
+            if (skip0) {
+                a.short_rows = R.short_rows + R.n_short0;
+                a.n_short = R.n_short - R.n_short0;
+            }
             a.n_long = R.n_long;
             a.n_hub = R.n_hub;
             a.W = g.W;
@@ -469,7 +476,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             a.neg_slope = d.negative_slope;
             {
                 const double loops = (mode != AGG_MEAN && (plan->flags & PEA_PLAN_SELF_LOOPS)) ? 1.0 : 0.0;
-                a.msgs_short = (double)R.edges_short + loops * R.n_short;
+                a.msgs_short = (double)R.edges_short + loops * a.n_short;
                 a.msgs_long = (double)R.edges_long + loops * (R.n_long - R.n_slots);
                 a.idx_share = mode == AGG_MEAN ? 1.0 : (double)g.n_convs;
             }
@@ -596,6 +603,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             return PEA_OK;
         }
         std::vector<GemmJob> jobs;
+        Level &Lp = m->levels[(size_t)s - 1];
         for (const Unit &u : L.units) {
             GemmJob J{};
             J.A1 = In + u.in_col;
@@ -609,6 +617,21 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             J.seg[0].c1 = u.HF;
             J.seg[0].dst = T + u.t_col;
             J.seg[0].ld = L.ld_t;
+            if (plan->flags & PEA_PLAN_SELF_LOOPS) {  // edge-less rows of the previous layer: read T_{s-1} (see run_groups)
+                for (const Unit &up : Lp.units) {
+                    if (up.p != u.p) continue;
+                    Relation &Rp = plan->rels[(size_t)up.rel];
+                    J.a1_mask = Rp.deg0;
+                    J.a1_alt = wsf + Lp.off_t + up.t_col;
+                    J.lda_alt = Lp.ld_t;
+                    J.a1_bias = pack + Lp.bias_off + up.t_col;
+                    if (kind == PEA_KIND_GCN) {
+                        const bool fc = d.gcn_deg_from_col != 0;
+                        PEA_TRY(ensure_dinv(plan, up.rel, fc, stream));
+                        J.a1_scale = fc ? Rp.dinv_col : Rp.dinv_row;
+                    }
+                }
+            }
             jobs.push_back(J);
         }
         return launch_gemm_batch(jobs.data(), (int)jobs.size(), own_rows, n_own, stream);

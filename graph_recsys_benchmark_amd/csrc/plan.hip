@@ -125,7 +125,7 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     R.e_kept = rp[(size_t)N];
 
     // ---- degree bins over the rows this rank owns (host; rowptr only) ----
-    std::vector<int> short_rows, hub_rows, hub_first, hub_count;
+    std::vector<int> zero_rows, short_rows, hub_rows, hub_first, hub_count;
     std::vector<LongItem> items;
     const int tile = plan->shard_tile, world = plan->shard_world, rank = plan->shard_rank;
     int max_deg = 0, slots = 0;
@@ -135,7 +135,9 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
         if (world > 1 && (int)((i / tile) % world) != rank) continue;
         R.rows_owned++;
         R.edges_owned += deg;
-        if (deg <= kShortDeg) {
+        if (deg == 0) {
+            zero_rows.push_back((int)i);
+        } else if (deg <= kShortDeg) {
             short_rows.push_back((int)i);
             R.edges_short += deg;
         } else if (deg <= kChunk) {
@@ -158,7 +160,15 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
                      [](const LongItem &a, const LongItem &b) { return (a.end - a.beg) > (b.end - b.beg); });
     R.max_deg = max_deg;
     R.edges_long = R.edges_owned - R.edges_short;
+    R.n_short0 = (int)zero_rows.size();
+    zero_rows.insert(zero_rows.end(), short_rows.begin(), short_rows.end());  // edge-less rows first
+    short_rows.swap(zero_rows);
     R.n_short = (int)short_rows.size();
+    {
+        std::vector<unsigned char> flag((size_t)N);
+        for (int64_t i = 0; i < N; ++i) flag[(size_t)i] = rp[(size_t)i + 1] == rp[(size_t)i];
+        PEA_TRY(upload(flag, &R.deg0));
+    }
     R.n_long = (int)items.size();
     R.n_hub = (int)hub_rows.size();
     R.n_slots = slots;
@@ -193,7 +203,7 @@ void free_relation(Relation &R) {
     (void)hipFree(R.col_slot); (void)hipFree(R.dinv_row_slot); (void)hipFree(R.dinv_col_slot);
     (void)hipFree(R.slot_of_node); (void)hipFree(R.need_rows);
     (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col);
-    (void)hipFree(R.short_rows); (void)hipFree(R.long_items);
+    (void)hipFree(R.short_rows); (void)hipFree(R.long_items); (void)hipFree(R.deg0);
     (void)hipFree(R.hub_rows); (void)hipFree(R.hub_first); (void)hipFree(R.hub_count);
 }
 
