@@ -43,7 +43,7 @@ SIGNATURES = {
     'pea_version': (C.c_char_p, []),
     'pea_last_error': (C.c_char_p, []),
     'pea_device_count': (_int, []),
-    'pea_plan_create': (_int, [_i64, _int, C.POINTER(_vp), C.POINTER(_i64), _int, _int, _int, _int, _vp, C.POINTER(_vp)]),
+    'pea_plan_create': (_int, [_i64, _int, C.POINTER(_vp), C.POINTER(_i64), _int, _int, _int, _int, _int, _vp, C.POINTER(_vp)]),
     'pea_plan_destroy': (_int, [_vp]),
     'pea_plan_relation_info': (_int, [_vp, _int, C.POINTER(_i64)]),
     'pea_plan_export_csr': (_int, [_vp, _int, _vp, _vp, _vp]),

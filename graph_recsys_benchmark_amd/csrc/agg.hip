@@ -187,6 +187,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + wave;
     if (item >= P.n_long) return;  // wave-uniform
     const LongItem it = P.long_items[item];
+    if (it.slot == -2) return;  // padding of the XCD-affine item layout (plan.hip)
     const int sub = lane / G, sl = lane % G;
     const bool active = sl * 4 < P.W;
     const int c4 = active ? sl * 4 : 0;
@@ -404,7 +405,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         if (g.n_long <= 0) continue;
         L.blk_start[L.n_groups] = blocks;
         L.g[L.n_groups++] = g;
-        blocks += (g.n_long + 3) / 4;
+        blocks += ((g.n_long + 3) / 4 + 7) / 8 * 8;  // groups start on a multiple of 8 workgroups (XCD round-robin)
     }
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {

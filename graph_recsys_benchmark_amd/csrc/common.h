@@ -53,6 +53,9 @@ class ProfScope {
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kShortDeg = 32;      // rows with <= this many kept edges go to the row-per-subgroup kernel
 constexpr int kChunk = 512;        // hub rows are cut into chunks of at most this many edges
+constexpr int64_t kSliceMinEdges = 2000000;   // relations below this are never source-sliced
+constexpr double kSliceBytes = 2.5e6;         // target gather footprint of one source slice (an XCD's L2 is 4 MiB)
+constexpr int kSliceMinSegment = 32;          // only rows with >= slices*this edges are cut per slice
 
 // One work item of the row-per-wave kernel: edges [beg, end) of `row`; slot < 0 writes the output row,
 // slot >= 0 writes a partial record (hub chunk) that the merge kernel folds in chunk order.
@@ -63,6 +66,9 @@ struct LongItem {
 struct Relation {
     int64_t e_in = 0;       // COO edges handed over
     int64_t e_kept = 0;     // after self-loop removal (if the plan does that)
+    int slices = 1;         // > 1: edges inside a row are grouped by source slice (8 XCDs x phases)
+    int slice_min = 0;
+    int64_t slice_span = 1;
     int max_deg = 0;
     int *rowptr = nullptr;  // device [N+1]
     int *col = nullptr;     // device [e_kept] source ids, destination-sorted, stable
@@ -72,7 +78,7 @@ struct Relation {
     int n_short = 0, n_short0 = 0;
     unsigned char *deg0 = nullptr;  // device [N]: 1 where the row has no kept edge (self loop only)
     LongItem *long_items = nullptr;
-    int n_long = 0;
+    int n_long = 0, n_direct = 0;  // n_direct: items that finish their row themselves (slot == -1)
     int *hub_rows = nullptr, *hub_first = nullptr, *hub_count = nullptr;  // per hub row: first slot, #chunks
     int n_hub = 0, n_slots = 0;
     int64_t rows_owned = 0, edges_owned = 0;
@@ -92,6 +98,7 @@ struct pea_plan {
     int64_t N = 0;
     int flags = 0;
     int shard_rank = 0, shard_world = 1, shard_tile = 256;
+    int gather_row_bytes = 0;  // hint: bytes of one gathered source row (0 = never slice by source)
     std::vector<pea::Relation> rels;
     int max_slots = 0;  // max hub chunks over relations (sizes the partial workspace)
     int *owned_rows = nullptr;  // device, sharded plans only

@@ -477,7 +477,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             {
                 const double loops = (mode != AGG_MEAN && (plan->flags & PEA_PLAN_SELF_LOOPS)) ? 1.0 : 0.0;
                 a.msgs_short = (double)R.edges_short + loops * a.n_short;
-                a.msgs_long = (double)R.edges_long + loops * (R.n_long - R.n_slots);
+                a.msgs_long = (double)R.edges_long + loops * R.n_direct;
                 a.idx_share = mode == AGG_MEAN ? 1.0 : (double)g.n_convs;
             }
             if (mode == AGG_MEAN) {

@@ -34,6 +34,55 @@ __global__ void coo_to_keys(int64_t E, int64_t N, const int64_t *__restrict__ co
     vals[e] = (int)j;
 }
 
+// (dst, source-slice) keys: inside a destination row the edges are grouped by which slice of the source-id range
+// they gather from, so a workgroup can be handed edges whose source rows share one XCD's L2
+__global__ void keys_with_slice(int64_t E, int64_t N, const int *__restrict__ keys, const int *__restrict__ vals, int smin,
+                                int64_t span, int S, unsigned long long *__restrict__ keys64) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int k = keys[e];
+    int sl = 0;
+    if (k < (int)N) sl = (int)(((int64_t)(vals[e] - smin) * S) / span);
+    keys64[e] = (unsigned long long)k * (unsigned)S + (unsigned)sl;
+}
+
+__global__ void src_range(int64_t E, int64_t N, const int *__restrict__ keys, const int *__restrict__ vals, int *mn, int *mx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E || keys[e] >= (int)N) return;
+    atomicMin(mn, vals[e]);
+    atomicMax(mx, vals[e]);
+}
+
+__global__ void rowptr_from_sorted64(int64_t E, int64_t N, int S, const unsigned long long *__restrict__ keys,
+                                     int *__restrict__ rowptr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    const unsigned long long want = (unsigned long long)i * (unsigned)S;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    rowptr[i] = (int)lo;
+}
+
+// bounds[h*(S+1) + s] = first edge of hub row rows[h] whose slice is >= s
+__global__ void slice_bounds(int n_hub, int S, int64_t E, const int *__restrict__ rows, const unsigned long long *__restrict__ keys,
+                             int *__restrict__ bounds) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_hub * (S + 1)) return;
+    const int h = t / (S + 1), sl = t % (S + 1);
+    const unsigned long long want = (unsigned long long)rows[h] * (unsigned)S + (unsigned)sl;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    bounds[t] = (int)lo;
+}
+
 // rowptr[i] = first position whose key >= i  (i = 0..N)
 __global__ void rowptr_from_sorted(int64_t E, int64_t N, const int *__restrict__ keys, int *__restrict__ rowptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,11 +126,18 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     PEA_REQUIRE(E >= 0 && E < (int64_t)INT32_MAX - 64, PEA_ERR_ARG, "relation with %lld edges exceeds the int32 CSR", (long long)E);
     PEA_HIP(hipMalloc((void **)&R.rowptr, (size_t)(N + 1) * sizeof(int)));
     int *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *err = nullptr;
+    unsigned long long *k64_in = nullptr, *k64_out = nullptr;
+    int *hub_dev = nullptr, *bounds_dev = nullptr;
+    int S = 1;  // source slices (1 = edge order inside a row is plain COO order)
     void *tmp = nullptr;
     int rc = PEA_OK;
     const size_t eb = (size_t)std::max<int64_t>(E, 1) * sizeof(int);
     auto cleanup = [&]() {
         (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(err); (void)hipFree(tmp);
+        (void)hipFree(k64_in); (void)hipFree(k64_out); (void)hipFree(hub_dev); (void)hipFree(bounds_dev);
+        keys_in = keys_out = vals_in = err = hub_dev = bounds_dev = nullptr;
+        k64_in = k64_out = nullptr;
+        tmp = nullptr;
     };
 #define PEA_HIP_C(call)                                                                                   \
     do {                                                                                                  \
@@ -104,28 +160,72 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
         PEA_HIP_C(hipGetLastError());
         int bits = 1;
         while ((1ll << bits) <= N) ++bits;  // keys are in [0, N]
+        // Large relations whose source rows overflow an XCD's 4 MiB L2: group each row's edges by source slice
+        // (8 XCDs x phases), SURVEY.md section 7 "gather granularity" / guide: run workgroups that share rows on one XCD
+        // (PEA_SLICE_MIN_EDGES / PEA_SLICE_BYTES: test knobs so small graphs can exercise the sliced layout)
+        const char *env_e = getenv("PEA_SLICE_MIN_EDGES"), *env_b = getenv("PEA_SLICE_BYTES");
+        const int64_t min_edges = env_e ? atoll(env_e) : kSliceMinEdges;
+        const double slice_bytes = env_b ? atof(env_b) : kSliceBytes;
+        if (plan->gather_row_bytes > 0 && E >= min_edges) {
+            int h_mm[2] = {INT32_MAX, -1}, *mm = nullptr;
+            PEA_HIP_C(hipMalloc((void **)&mm, 2 * sizeof(int)));
+            PEA_HIP_C(hipMemcpyAsync(mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(src_range, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, E, N, keys_in, vals_in, mm, mm + 1);
+            PEA_HIP_C(hipMemcpyAsync(h_mm, mm, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
+            PEA_HIP_C(hipStreamSynchronize(stream));
+            (void)hipFree(mm);
+            if (h_mm[1] >= h_mm[0]) {
+                const int64_t span = (int64_t)h_mm[1] - h_mm[0] + 1;
+                const double footprint = (double)span * plan->gather_row_bytes;
+                if (footprint > 1.5 * slice_bytes) {
+                    const int phases = (int)std::min<double>(8.0, std::ceil(footprint / (8.0 * slice_bytes)));
+                    S = 8 * phases;
+                    R.slice_min = h_mm[0];
+                    R.slice_span = span;
+                }
+            }
+        }
         size_t tmp_bytes = 0;
-        PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
-                                            (unsigned)bits, stream));
-        PEA_HIP_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-        PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
-                                            (unsigned)bits, stream));
+        if (S == 1) {
+            PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
+                                                (unsigned)bits, stream));
+            PEA_HIP_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+            PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
+                                                (unsigned)bits, stream));
+        } else {
+            PEA_HIP_C(hipMalloc((void **)&k64_in, (size_t)E * sizeof(unsigned long long)));
+            PEA_HIP_C(hipMalloc((void **)&k64_out, (size_t)E * sizeof(unsigned long long)));
+            hipLaunchKernelGGL(keys_with_slice, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, E, N, keys_in, vals_in,
+                               R.slice_min, R.slice_span, S, k64_in);
+            PEA_HIP_C(hipGetLastError());
+            int sbits = 1;
+            while ((1 << sbits) < S) ++sbits;
+            PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k64_in, k64_out, vals_in, R.col, (size_t)E, 0u,
+                                                (unsigned)(bits + sbits + 1), stream));
+            PEA_HIP_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+            PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, k64_in, k64_out, vals_in, R.col, (size_t)E, 0u,
+                                                (unsigned)(bits + sbits + 1), stream));
+        }
     }
-    hipLaunchKernelGGL(rowptr_from_sorted, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, stream, E, N, keys_out,
-                       R.rowptr);
+    if (S == 1)
+        hipLaunchKernelGGL(rowptr_from_sorted, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, stream, E, N, keys_out,
+                           R.rowptr);
+    else
+        hipLaunchKernelGGL(rowptr_from_sorted64, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, stream, E, N, S, k64_out,
+                           R.rowptr);
     PEA_HIP_C(hipGetLastError());
     int herr = 0;
     PEA_HIP_C(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     std::vector<int> rp((size_t)N + 1);
     PEA_HIP_C(hipMemcpyAsync(rp.data(), R.rowptr, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
     PEA_HIP_C(hipStreamSynchronize(stream));
-    cleanup();
-#undef PEA_HIP_C
+    if (herr != 0) cleanup();
     PEA_REQUIRE(herr == 0, PEA_ERR_RANGE, "edge_index holds a node id outside [0, %lld)", (long long)N);
     R.e_kept = rp[(size_t)N];
+    R.slices = S;
 
     // ---- degree bins over the rows this rank owns (host; rowptr only) ----
-    std::vector<int> zero_rows, short_rows, hub_rows, hub_first, hub_count;
+    std::vector<int> zero_rows, short_rows, hub_rows, hub_first, hub_count, sliced_rows;
     std::vector<LongItem> items;
     const int tile = plan->shard_tile, world = plan->shard_world, rank = plan->shard_rank;
     int max_deg = 0, slots = 0;
@@ -142,6 +242,8 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
             R.edges_short += deg;
         } else if (deg <= kChunk) {
             items.push_back({(int)i, rp[(size_t)i], rp[(size_t)i + 1], -1});
+        } else if (S > 1 && deg >= S * kSliceMinSegment) {
+            sliced_rows.push_back((int)i);  // chunked per source slice below
         } else {
             const int nch = (deg + kChunk - 1) / kChunk;
             const int len = (deg + nch - 1) / nch;
@@ -158,6 +260,62 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     // longest first: the tail of the launch is made of the cheapest items
     std::stable_sort(items.begin(), items.end(),
                      [](const LongItem &a, const LongItem &b) { return (a.end - a.beg) > (b.end - b.beg); });
+    if (!sliced_rows.empty()) {
+        // per-slice segments of the big hub rows -> chunks, laid out so that workgroup b (4 items) of the launch
+        // works on slice  phase*8 + (b % 8): workgroups are dealt round-robin over the 8 XCDs, so all gathers of
+        // one slice meet in one XCD's L2 (placement affects speed only, never results)
+        const int nh = (int)sliced_rows.size();
+        std::vector<int> bounds((size_t)nh * (S + 1));
+#define PEA_HIP_C2(call)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));          \
+            cleanup();                                                                                    \
+            return PEA_ERR_HIP;                                                                           \
+        }                                                                                                 \
+    } while (0)
+        PEA_HIP_C2(hipMalloc((void **)&hub_dev, (size_t)nh * sizeof(int)));
+        PEA_HIP_C2(hipMalloc((void **)&bounds_dev, bounds.size() * sizeof(int)));
+        PEA_HIP_C2(hipMemcpyAsync(hub_dev, sliced_rows.data(), (size_t)nh * sizeof(int), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(slice_bounds, dim3((unsigned)((bounds.size() + 255) / 256)), dim3(256), 0, stream, nh, S, E, hub_dev,
+                           k64_out, bounds_dev);
+        PEA_HIP_C2(hipGetLastError());
+        PEA_HIP_C2(hipMemcpyAsync(bounds.data(), bounds_dev, bounds.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+        PEA_HIP_C2(hipStreamSynchronize(stream));
+#undef PEA_HIP_C2
+        std::vector<std::vector<LongItem>> per_slice((size_t)S);
+        for (int h = 0; h < nh; ++h) {
+            hub_rows.push_back(sliced_rows[(size_t)h]);
+            hub_first.push_back(slots);
+            int count = 0;
+            for (int sl = 0; sl < S; ++sl) {
+                const int b0 = bounds[(size_t)h * (S + 1) + sl], e0 = bounds[(size_t)h * (S + 1) + sl + 1];
+                if (e0 <= b0) continue;
+                const int nch = (e0 - b0 + kChunk - 1) / kChunk, len = (e0 - b0 + nch - 1) / nch;
+                for (int c = 0; c < nch; ++c) {
+                    const int b = b0 + c * len;
+                    per_slice[(size_t)sl].push_back({sliced_rows[(size_t)h], b, std::min(b + len, e0), slots++});
+                    ++count;
+                }
+            }
+            hub_count.push_back(count);
+        }
+        std::vector<LongItem> head;
+        const LongItem pad = {0, 0, 0, -2};
+        for (int ph = 0; ph < S / 8; ++ph) {
+            size_t rounds = 0;
+            for (int x = 0; x < 8; ++x) rounds = std::max(rounds, (per_slice[(size_t)ph * 8 + x].size() + 3) / 4);
+            for (size_t q = 0; q < rounds; ++q)
+                for (int x = 0; x < 8; ++x) {
+                    const std::vector<LongItem> &v = per_slice[(size_t)ph * 8 + x];
+                    for (size_t w = 0; w < 4; ++w) head.push_back(q * 4 + w < v.size() ? v[q * 4 + w] : pad);
+                }
+        }
+        head.insert(head.end(), items.begin(), items.end());
+        items.swap(head);
+    }
+    cleanup();
     R.max_deg = max_deg;
     R.edges_long = R.edges_owned - R.edges_short;
     R.n_short0 = (int)zero_rows.size();
@@ -170,6 +328,8 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
         PEA_TRY(upload(flag, &R.deg0));
     }
     R.n_long = (int)items.size();
+    R.n_direct = 0;
+    for (const LongItem &it : items) R.n_direct += it.slot == -1;
     R.n_hub = (int)hub_rows.size();
     R.n_slots = slots;
     plan->max_slots = std::max(plan->max_slots, slots);
@@ -180,6 +340,7 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     PEA_TRY(upload(hub_count, &R.hub_count));
     (void)rc;
     return PEA_OK;
+#undef PEA_HIP_C
 }
 
 __global__ void rename_sources(int64_t E, const int *__restrict__ col, const int *__restrict__ slot_of_node,
@@ -300,8 +461,8 @@ extern "C" int pea_plan_set_sources(pea_plan *plan, int relation, const int32_t 
 }
 
 extern "C" int pea_plan_create(int64_t num_nodes, int n_relations, const int64_t *const *coo_host,
-                               const int64_t *num_edges_host, int flags, int shard_rank, int shard_world,
-                               int shard_tile, void *stream_, pea_plan **out) {
+                               const int64_t *num_edges_host, int flags, int gather_row_bytes, int shard_rank,
+                               int shard_world, int shard_tile, void *stream_, pea_plan **out) {
     using namespace pea;
     hipStream_t stream = (hipStream_t)stream_;
     PEA_REQUIRE(out != nullptr, PEA_ERR_ARG, "plan: out is null");
@@ -314,6 +475,7 @@ extern "C" int pea_plan_create(int64_t num_nodes, int n_relations, const int64_t
     pea_plan *plan = new pea_plan();
     plan->N = num_nodes;
     plan->flags = flags;
+    plan->gather_row_bytes = gather_row_bytes > 0 ? gather_row_bytes : 0;
     plan->shard_rank = shard_rank;
     plan->shard_world = shard_world;
     plan->shard_tile = shard_tile;
@@ -344,6 +506,7 @@ extern "C" int pea_plan_relation_info(const pea_plan *plan, int relation, int64_
     const pea::Relation &R = plan->rels[(size_t)relation];
     info[0] = R.e_kept; info[1] = R.max_deg; info[2] = R.n_short; info[3] = R.n_long;
     info[4] = R.n_hub; info[5] = R.n_slots; info[6] = R.rows_owned; info[7] = R.edges_owned;
+    info[8] = R.slices;
     return PEA_OK;
 }
 

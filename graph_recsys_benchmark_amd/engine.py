@@ -39,7 +39,7 @@ class GraphPlan:
     """
 
     def __init__(self, num_nodes, meta_path_edge_index_list, self_loops, shard_rank=0, shard_world=1,
-                 shard_tile=256):
+                 shard_tile=256, gather_row_bytes=256):
         lib = _lib.require_device()
         self.num_nodes = int(num_nodes)
         self.self_loops = bool(self_loops)
@@ -71,8 +71,8 @@ class GraphPlan:
         nedge = (C.c_int64 * len(uniq))(*[t.shape[1] for t in uniq])
         handle = C.c_void_p()
         _lib.check(lib.pea_plan_create(self.num_nodes, len(uniq), ptrs, nedge,
-                                       _lib.PLAN_SELF_LOOPS if self_loops else 0, self.shard[0], self.shard[1],
-                                       self.shard[2], _lib.current_stream(), C.byref(handle)))
+                                       _lib.PLAN_SELF_LOOPS if self_loops else 0, int(gather_row_bytes), self.shard[0],
+                                       self.shard[1], self.shard[2], _lib.current_stream(), C.byref(handle)))
         self._h = handle
         self.device = uniq[0].device
         self.layout = ShardLayout(self.num_nodes, *self.shard)
@@ -88,9 +88,10 @@ class GraphPlan:
                 self.source_layouts[r] = lay
 
     def relation_info(self, r):
-        info = (C.c_int64 * 8)()
+        info = (C.c_int64 * 9)()
         _lib.check(_lib.load().pea_plan_relation_info(self._h, r, info))
-        names = ('edges', 'max_degree', 'short_rows', 'long_items', 'hub_rows', 'hub_chunks', 'rows_owned', 'edges_owned')
+        names = ('edges', 'max_degree', 'short_rows', 'long_items', 'hub_rows', 'hub_chunks', 'rows_owned', 'edges_owned',
+                 'slices')
         return dict(zip(names, [int(v) for v in info]))
 
     def export_csr(self, r):

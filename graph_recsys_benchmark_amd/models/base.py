@@ -147,7 +147,8 @@ class PEABaseRecsysModel(GraphRecsysModel):
             emb, hidden, repr_dim, heads = self._dims
             plan = _engine.GraphPlan(self.x.shape[0], self.meta_path_edge_index_list,
                                      self_loops=self.kind in ('gat', 'gcn'), shard_rank=self._shard[0],
-                                     shard_world=self._shard[1], shard_tile=self._shard[2])
+                                     shard_world=self._shard[1], shard_tile=self._shard[2],
+                                     gather_row_bytes=4 * hidden * (heads if self.kind == 'gat' else 1))
             self._engine = _engine.PEAEngine(plan, self.kind, self.meta_path_steps, emb, hidden, repr_dim,
                                              heads=heads if self.kind == 'gat' else 1,
                                              channel_aggr=self.channel_aggr, gcn_deg_from=self.gcn_deg_from)

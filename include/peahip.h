@@ -74,15 +74,19 @@ int pea_device_count(void);
  * coo_host[r] : DEVICE pointer to relation r's int64 [2, num_edges[r]] row-major COO
  *               (row 0 = source j, row 1 = target i: PyG flow source_to_target); the array of
  *               pointers itself lives on the host.
+ * gather_row_bytes : hint, bytes of one gathered source row (e.g. 4*hidden_size*heads).  When a relation has
+ *               >= 2 M edges and its source rows overflow an XCD's L2, the edges of its big hub rows are grouped
+ *               by source-id slice and laid out so that one XCD works on one slice at a time (speed only;
+ *               the edge order inside such rows is then (slice, COO order)).  0 = plain COO order everywhere.
  * shard_*     : destination-row ownership for multi-GPU runs: row i belongs to rank
  *               (i / shard_tile) % shard_world.  world = 1 -> every row.
  * ---------------------------------------------------------------------------------------------- */
 int pea_plan_create(int64_t num_nodes, int n_relations, const int64_t *const *coo_host,
-                    const int64_t *num_edges_host, int flags, int shard_rank, int shard_world,
-                    int shard_tile, void *stream, pea_plan **out);
+                    const int64_t *num_edges_host, int flags, int gather_row_bytes, int shard_rank,
+                    int shard_world, int shard_tile, void *stream, pea_plan **out);
 int pea_plan_destroy(pea_plan *plan);
-/* info_host[0..7] = {edges kept, max in-degree, #short rows, #long items, #hub rows, #hub chunks,
- *                    rows owned, edges owned} for one relation */
+/* info_host[0..8] = {edges kept, max in-degree, #short rows, #long items, #hub rows, #hub chunks,
+ *                    rows owned, edges owned, source slices} for one relation */
 int pea_plan_relation_info(const pea_plan *plan, int relation, int64_t *info_host);
 /* copies the CSR of one relation back (tests): rowptr int32 [N+1], col int32 [edges kept] (device) */
 int pea_plan_export_csr(const pea_plan *plan, int relation, int32_t *rowptr, int32_t *col, void *stream);

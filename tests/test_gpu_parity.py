@@ -149,3 +149,29 @@ def test_error_behaviour():
         model.loss(torch.from_numpy(g.batch).cuda())
     with pytest.raises(NotImplementedError):
         build_model('gat', g.meta['num_nodes'], g.edges, g.steps, 32, 24, 16, channel_aggr='concat').eval()
+
+
+def test_source_sliced_hub_rows_match_oracle(monkeypatch):
+    """Large relations get their hub rows cut per source slice (XCD-affine layout, csrc/plan.hip); shrink the
+    thresholds so a small graph takes that path, and check results and plan shape."""
+    monkeypatch.setenv('PEA_SLICE_MIN_EDGES', '1000')
+    monkeypatch.setenv('PEA_SLICE_BYTES', '20000')
+    n, blocks, rel = random_hin(31, n_user=5000, n_item=400, n_attr=30, e_u2i=90000, e_attr=2000)
+    u2i, a2i = rel['u2i'], rel['a2i']
+    flip = lambda e: np.ascontiguousarray(e[::-1])
+    edges = [[u2i, flip(u2i)], [a2i, flip(u2i)], [flip(u2i), u2i]]
+    steps = [2, 2, 2]
+    for kind in ('gat', 'gcn', 'sage'):
+        model = build_model(kind, n, edges, steps, 64, 64, 16)
+        model.load_state_dict(random_state_dict(model, 6))
+        model.eval()
+        with torch.no_grad():
+            fused, stack = model.forward(return_stack=True)
+        plan = model._engine.plan
+        info = plan.relation_info(plan.relation_of[0][0])          # user -> item: hub items, 5000 source users
+        assert info['slices'] >= 8 and info['hub_chunks'] > info['hub_rows'] >= 1
+        sd, cps, hls = _oracle_model(kind, model, edges, steps, 1)
+        want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, hls, att=sd.get('att'), return_stack=True)
+        t_fused, t_stack = f64_forward(kind, sd, edges, steps, 1, 'att')
+        assert_fp32_close(_np(stack), wstack, t_stack, what=kind + ' stack')
+        assert_fp32_close(_np(fused), want, t_fused, what=kind + ' fused')
