@@ -45,10 +45,12 @@ struct Soft {
     float m, s;
     float4 acc;
     __device__ __forceinline__ void init() { m = kNegBig; s = 0.f; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
-    // one exp per edge: x = exp(-|e - m|) rescales either the state (new max) or the newcomer
+    // logits live in the log2 domain (the packed att vectors carry the log2(e) factor; leaky_relu is positively
+    // homogeneous), so a weight is one v_exp_f32.  One exp per edge: x = 2^-|e - m| rescales either the state
+    // (new max) or the newcomer.
     __device__ __forceinline__ void push(float e, float4 h) {
         const float d = e - m;
-        const float x = __expf(-fabsf(d));
+        const float x = __builtin_amdgcn_exp2f(-fabsf(d));
         const bool up = d > 0.f;
         const float fs = up ? x : 1.f;   // factor on the old state
         const float p = up ? 1.f : x;    // weight of the new edge
@@ -61,21 +63,43 @@ struct Soft {
     }
     __device__ __forceinline__ void merge(float m2, float s2, float4 a2) {
         const float mn = fmaxf(m, m2);
-        const float f1 = __expf(m - mn), f2 = __expf(m2 - mn);
+        const float f1 = __builtin_amdgcn_exp2f(m - mn), f2 = __builtin_amdgcn_exp2f(m2 - mn);
         s = s * f1 + s2 * f2;
         acc = add4(scale4(acc, f1), scale4(a2, f2));
         m = mn;
     }
 };
 
-__device__ __forceinline__ float leaky(float a, float slope) { return a > 0.f ? a : a * slope; }
+// slope in [0, 1] (checked on the host): leaky_relu(a) = max(a, slope * a)
+__device__ __forceinline__ float leaky(float a, float slope) { return fmaxf(a, a * slope); }
 
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+// row j of a [rows, ld] fp32 matrix: one 32x32->64 multiply-add, no sign extension
+__device__ __forceinline__ const float *row_at(const float *base, int j, int ld) {
+    return base + (unsigned long long)(unsigned)j * (unsigned)ld;
+}
+
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
 
 // Sum of v over the F4 = F/4 consecutive lanes that hold one attention head's columns (every lane of the
 // head gets the total).  The logit (x_i.att_i).sum(-1) + (x_j.att_j).sum(-1) of GATConv.message is thus
 // computed from the gathered row itself: no per-node attention scalars are stored or gathered.
+// F4T > 0: head width known at compile time (a power of two): constant-offset xor shuffles (DPP / swizzle).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {  // v from the lane the DPP control selects (all rows, all banks)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+template <int F4T>
 __device__ __forceinline__ float head_sum(float v, int lane, int pos, int F4, bool pow2) {
+    if (F4T > 0) {  // all-reduce inside aligned power-of-two lane groups with data-parallel primitives (no LDS crossbar)
+        if (F4T >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+        if (F4T >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+        if (F4T >= 8) v += dpp_f<0x141>(v);   // row_half_mirror: the other quad of the 8-lane half
+        if (F4T >= 16) v += dpp_f<0x140>(v);  // row_mirror: the other half of the 16-lane row
+        if (F4T >= 32) v += __shfl_xor(v, 16);
+        if (F4T >= 64) v += __shfl_xor(v, 32);
+        return v;
+    }
     if (pow2) {
         for (int off = 1; off < F4; off <<= 1) v += __shfl_xor(v, off);
         return v;
@@ -113,7 +137,7 @@ __device__ __forceinline__ void finish_row(const AggGroup &P, int row, int c4, i
 // ------------------------------------------------------------------------------------------------
 // short rows: one G-lane subgroup per destination row
 // ------------------------------------------------------------------------------------------------
-template <int G, int MODE>
+template <int G, int MODE, int F4T>
 __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     const int gi = find_group(L);
     const AggGroup &P = L.g[gi];
@@ -138,8 +162,8 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
         att_s = ld4(P.att_src + c4);
-        h_self = ld4(feat_self + (size_t)row * P.ld_self);
-        a_d = head_sum(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
+        h_self = ld4(row_at(feat_self, row, P.ld_self));
+        a_d = head_sum<F4T>(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
     } else if (MODE == AGG_GCN) {
         di = P.dinv_self[row];
     }
@@ -153,9 +177,9 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
         const int e = beg + t;
         const bool ok = e < end;
         const int j = ok ? P.col[e] : 0;
-        const float4 h = ld4(feat + (size_t)j * P.ld_feat);
+        const float4 h = ld4(row_at(feat, j, P.ld_feat));
         if (MODE == AGG_GAT) {
-            const float a = head_sum(dot4(h, att_s), lane, pos, F4, pow2);
+            const float a = head_sum<F4T>(dot4(h, att_s), lane, pos, F4, pow2);
             if (ok) st.push(leaky(a + a_d, P.neg_slope), h);
         } else if (MODE == AGG_GCN) {
             sum = fma4(P.dinv[j] * di, h, sum);
@@ -165,10 +189,10 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     }
     if (P.self_loop) {
         if (MODE == AGG_GAT) {
-            const float a = head_sum(dot4(h_self, att_s), lane, pos, F4, pow2);
+            const float a = head_sum<F4T>(dot4(h_self, att_s), lane, pos, F4, pow2);
             st.push(leaky(a + a_d, P.neg_slope), h_self);
         } else if (MODE == AGG_GCN) {
-            sum = fma4(di * di, ld4(feat_self + (size_t)row * P.ld_self), sum);
+            sum = fma4(di * di, ld4(row_at(feat_self, row, P.ld_self)), sum);
         }
     }
     if (active) finish_row<MODE>(P, row, c4, end - beg, st, sum);
@@ -177,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
 // ------------------------------------------------------------------------------------------------
 // long rows and hub chunks: one wave per item
 // ------------------------------------------------------------------------------------------------
-template <int G, int MODE>
+template <int G, int MODE, int F4T>
 __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     constexpr int NSG = kWave / G;
     const int gi = find_group(L);
@@ -205,8 +229,8 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
         att_s = ld4(P.att_src + c4);
-        h_self = ld4(feat_self + (size_t)row * P.ld_self);
-        a_d = head_sum(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
+        h_self = ld4(row_at(feat_self, row, P.ld_self));
+        a_d = head_sum<F4T>(dot4(h_self, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
     } else if (MODE == AGG_GCN) {
         di = P.dinv_self[row];
     }
@@ -230,12 +254,12 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                h[u] = ld4(feat + (size_t)jj[u] * P.ld_feat);
+                h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
                 if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
             }
             if (MODE == AGG_GAT) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) a[u] = head_sum(dot4(h[u], att_s), lane, pos, F4, pow2);
+                for (int u = 0; u < U; ++u) a[u] = head_sum<F4T>(dot4(h[u], att_s), lane, pos, F4, pow2);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -279,10 +303,10 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     }
     if (P.self_loop) {
         if (MODE == AGG_GAT) {
-            const float a = head_sum(dot4(h_self, att_s), lane, pos, F4, pow2);
+            const float a = head_sum<F4T>(dot4(h_self, att_s), lane, pos, F4, pow2);
             st.push(leaky(a + a_d, P.neg_slope), h_self);
         } else if (MODE == AGG_GCN) {
-            sum = fma4(di * di, ld4(feat_self + (size_t)row * P.ld_self), sum);
+            sum = fma4(di * di, ld4(row_at(feat_self, row, P.ld_self)), sum);
         }
     }
     if (sub == 0 && active) finish_row<MODE>(P, row, c4, it.end - it.beg, st, sum);
@@ -291,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
 // ------------------------------------------------------------------------------------------------
 // hub rows: fold the chunk records in chunk order, add the self loop, finish
 // ------------------------------------------------------------------------------------------------
-template <int G, int MODE>
+template <int G, int MODE, int F4T>
 __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
     constexpr int NSG = kWave / G;
     const int gi = find_group(L);
@@ -333,12 +357,12 @@ __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
     }
     const float *feat_self = P.feat_self + c4;
     if (P.self_loop) {
-        const float4 h = ld4(feat_self + (size_t)row * P.ld_self);
+        const float4 h = ld4(row_at(feat_self, row, P.ld_self));
         if (MODE == AGG_GAT) {
             const int F4 = P.F / 4, pos = sl % F4;
             const bool pow2 = (F4 & (F4 - 1)) == 0;
-            const float a_d = head_sum(dot4(h, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
-            const float a = head_sum(dot4(h, ld4(P.att_src + c4)), lane, pos, F4, pow2);
+            const float a_d = head_sum<F4T>(dot4(h, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
+            const float a = head_sum<F4T>(dot4(h, ld4(P.att_src + c4)), lane, pos, F4, pow2);
             st.push(leaky(a + a_d, P.neg_slope), h);
         } else if (MODE == AGG_GCN) {
             const float di = P.dinv_self[row];
@@ -369,7 +393,7 @@ const char *kname(int which) {
     return names[which];
 }
 
-template <int G, int MODE>
+template <int G, int MODE, int F4T>
 int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
     AggLaunch L;
     // algorithmic bytes of SURVEY.md 8(d) attributed to a launch: per message 4 B per gathered feature column
@@ -394,7 +418,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
         ProfScope ps(kname<G, MODE>(0), stream, bytes_short);
-        hipLaunchKernelGGL((agg_short_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        hipLaunchKernelGGL((agg_short_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
     // long + hub chunks
@@ -410,7 +434,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
         ProfScope ps(kname<G, MODE>(1), stream, bytes_long);
-        hipLaunchKernelGGL((agg_long_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        hipLaunchKernelGGL((agg_long_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
     // hub merge
@@ -426,25 +450,44 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
         ProfScope ps(kname<G, MODE>(2), stream, 0.0);
-        hipLaunchKernelGGL((agg_merge_kernel<G, MODE>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        hipLaunchKernelGGL((agg_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
     return PEA_OK;
 }
 
+// head-width class of a group: the common widths get compile-time shuffles
+int f4_class(int mode, int G, int F) {
+    if (mode != AGG_GAT) return 0;
+    const int f4 = F / 4;
+    return f4 == G ? G : f4 == 4 ? 4 : 0;
+}
+
+template <int G, int MODE>
+int launch_g(const AggLaunch &base, int cls, const int *sel, int n, hipStream_t stream) {
+    if (MODE == AGG_GAT && cls == G) return launch_for_g<G, MODE, G>(base, sel, n, stream);
+    if (MODE == AGG_GAT && cls == 4) return launch_for_g<G, MODE, (G >= 4 ? 4 : 0)>(base, sel, n, stream);
+    return launch_for_g<G, MODE, 0>(base, sel, n, stream);
+}
+
 template <int MODE>
 int launch_mode(const AggLaunch &base, hipStream_t stream) {
+    const int classes[3] = {0, 4, -1};  // -1 stands for "== G"
     for (int G = 4; G <= 64; G <<= 1) {
-        int sel[kMaxAggGroups], n = 0;
-        for (int i = 0; i < base.n_groups; ++i)
-            if (lanes_for(base.g[i].W) == G) sel[n++] = i;
-        if (!n) continue;
-        switch (G) {
-            case 4: PEA_TRY((launch_for_g<4, MODE>(base, sel, n, stream))); break;
-            case 8: PEA_TRY((launch_for_g<8, MODE>(base, sel, n, stream))); break;
-            case 16: PEA_TRY((launch_for_g<16, MODE>(base, sel, n, stream))); break;
-            case 32: PEA_TRY((launch_for_g<32, MODE>(base, sel, n, stream))); break;
-            default: PEA_TRY((launch_for_g<64, MODE>(base, sel, n, stream))); break;
+        for (int ci = 0; ci < 3; ++ci) {
+            const int cls = classes[ci] < 0 ? G : classes[ci];
+            if (ci == 1 && G == 4) continue;  // class 4 == class G there
+            int sel[kMaxAggGroups], n = 0;
+            for (int i = 0; i < base.n_groups; ++i)
+                if (lanes_for(base.g[i].W) == G && f4_class(MODE, G, base.g[i].F) == cls) sel[n++] = i;
+            if (!n) continue;
+            switch (G) {
+                case 4: PEA_TRY((launch_g<4, MODE>(base, cls, sel, n, stream))); break;
+                case 8: PEA_TRY((launch_g<8, MODE>(base, cls, sel, n, stream))); break;
+                case 16: PEA_TRY((launch_g<16, MODE>(base, cls, sel, n, stream))); break;
+                case 32: PEA_TRY((launch_g<32, MODE>(base, cls, sel, n, stream))); break;
+                default: PEA_TRY((launch_g<64, MODE>(base, cls, sel, n, stream))); break;
+            }
         }
     }
     return PEA_OK;
@@ -468,6 +511,8 @@ int launch_aggregate(AggMode mode, const AggGroup *groups, int n_groups, hipStre
         PEA_REQUIRE(g.ld_feat % 4 == 0 && g.ld_out % 4 == 0, PEA_ERR_ARG,
                     "aggregate: row strides must be multiples of 4 floats");
         PEA_REQUIRE(g.n_hub == 0 || g.partial != nullptr, PEA_ERR_ARG, "aggregate: hub rows need a partial buffer");
+        PEA_REQUIRE(mode != AGG_GAT || (g.neg_slope >= 0.f && g.neg_slope <= 1.f), PEA_ERR_ARG,
+                    "aggregate: negative_slope %g outside [0, 1] is not supported", (double)g.neg_slope);
         base.g[i] = g;
     }
     switch (mode) {
