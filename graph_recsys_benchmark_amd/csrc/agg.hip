@@ -261,14 +261,33 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) a[u] = head_sum<F4T>(dot4(h[u], att_s), lane, pos, F4, pow2);
             }
+            if (MODE == AGG_GAT) {
+                // one softmax update for the U edges: shared new max, one rescale of the state, U weights
+                float e[U];
+                float mn = st.m;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (MODE == AGG_GAT) {
-                    if (ok[u]) st.push(leaky(a[u] + a_d, P.neg_slope), h[u]);
-                } else if (MODE == AGG_GCN) {
-                    sum = fma4(ok[u] ? a[u] * di : 0.f, h[u], sum);
-                } else {
-                    if (ok[u]) sum = add4(sum, h[u]);
+                for (int u = 0; u < U; ++u) {
+                    e[u] = ok[u] ? leaky(a[u] + a_d, P.neg_slope) : -INFINITY;  // 2^(-inf - m) = 0
+                    mn = fmaxf(mn, e[u]);
+                }
+                const float fs = __builtin_amdgcn_exp2f(st.m - mn);
+                st.m = mn;
+                st.s *= fs;
+                st.acc = scale4(st.acc, fs);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float p = __builtin_amdgcn_exp2f(e[u] - mn);  // 0 for the masked slots (mn is finite)
+                    st.s += p;
+                    st.acc = fma4(p, h[u], st.acc);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (MODE == AGG_GCN) {
+                        sum = fma4(ok[u] ? a[u] * di : 0.f, h[u], sum);
+                    } else {
+                        if (ok[u]) sum = add4(sum, h[u]);
+                    }
                 }
             }
         }

@@ -10,6 +10,8 @@
 // tile, keeps its A fragment in registers (lane (r, h) holds A[row r][k in h*KH .. h*KH+KH) -- the k order is
 // permuted identically on the B side, which a sum over k does not care about) and walks the job's 32-column tiles,
 // streaming the k-major B columns from L2.  No LDS, no barriers; 4 independent waves per block.
+#include <algorithm>
+
 #include "common.h"
 
 namespace pea {
@@ -25,35 +27,41 @@ struct GemmBatch {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Branch-free A fragment load: every lane issues all its float4 loads back to back (invalid rows / k-ranges are
+// clamped to a valid address and zeroed afterwards), then the edge-less-row transform is applied with selects.
 template <int KH>
 __device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, int kbase, float (&a)[KH]) {
     const int K = J.K1 + J.K2;
-    const bool alt = J.a1_mask && rv && J.a1_mask[srow];
+    const bool alt = J.a1_mask != nullptr && rv && J.a1_mask[srow] != 0;
     float sc = 1.f;
-    if (alt && J.a1_scale) {
+    if (J.a1_scale) {
         const float di = J.a1_scale[srow];
-        sc = di * di;
+        sc = alt ? di * di : 1.f;
+    }
+    const float *p1 = alt ? J.a1_alt + srow * J.lda_alt : J.A1 + srow * J.lda1;
+    const float *p2 = J.K2 > 0 ? J.A2 + srow * J.lda2 : p1;
+    float4 v[KH / 4], bv[KH / 4];
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+        const int k = kbase + q * 4;
+        const bool ok = k < K;
+        const float *p = (k < J.K1 || !ok) ? p1 + (ok ? k : 0) : p2 + (k - J.K1);
+        v[q] = ld4(p);
+        bv[q] = (J.a1_mask != nullptr && k < J.K1) ? ld4(J.a1_bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
         const int k = kbase + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rv && k < K) {
-            if (k >= J.K1) {
-                v = ld4(J.A2 + srow * J.lda2 + (k - J.K1));
-            } else if (alt) {
-                const float4 t = ld4(J.a1_alt + srow * J.lda_alt + k), b = ld4(J.a1_bias + k);
-                // same roundings as the aggregation kernel's finish_row: product, then + bias, then relu
-                v = make_float4(fmaxf(sc * t.x + b.x, 0.f), fmaxf(sc * t.y + b.y, 0.f), fmaxf(sc * t.z + b.z, 0.f),
-                                fmaxf(sc * t.w + b.w, 0.f));
-            } else {
-                v = ld4(J.A1 + srow * J.lda1 + k);
-            }
+        float4 t = v[q];
+        if (alt && k < J.K1) {  // same roundings as the aggregation kernel's finish_row: product, + bias, relu
+            t = make_float4(fmaxf(sc * t.x + bv[q].x, 0.f), fmaxf(sc * t.y + bv[q].y, 0.f), fmaxf(sc * t.z + bv[q].z, 0.f),
+                            fmaxf(sc * t.w + bv[q].w, 0.f));
         }
-        a[q * 4 + 0] = v.x;
-        a[q * 4 + 1] = v.y;
-        a[q * 4 + 2] = v.z;
-        a[q * 4 + 3] = v.w;
+        const bool keep = rv && k < K;
+        a[q * 4 + 0] = keep ? t.x : 0.f;
+        a[q * 4 + 1] = keep ? t.y : 0.f;
+        a[q * 4 + 2] = keep ? t.z : 0.f;
+        a[q * 4 + 3] = keep ? t.w : 0.f;
     }
 }
 
@@ -135,6 +143,87 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmBatch Bt, cons
     }
 }
 
+// Persistent variant (the default): every workgroup first copies the WHOLE k-major B of all its jobs into LDS
+// (the 9 first-layer transforms of the MovieLens model are one 64 x 596 block = 149 KiB of the CU's 160 KiB), then its
+// 16 waves walk (job, 32-row tile, column group) items with no barrier at all: A fragment from global, B fragment
+// from LDS, 32 MFMAs per 32x32 output tile, stores straight from the accumulators.
+constexpr int kColGroup = 5;       // 32-column tiles per item
+struct PersistArgs {
+    int n_items;                   // all jobs
+    int item_start[kMaxBatch + 1]; // first item of job j
+    int lds_off[kMaxBatch];        // float offset of job j's B image, row stride lds_ld[j]
+    int lds_ld[kMaxBatch];
+};
+
+extern __shared__ float g_lds[];
+
+template <int KH>
+__global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(const GemmBatch Bt, const PersistArgs Pa, const int *__restrict__ rows,
+                                                            int64_t n_rows) {
+    constexpr int NT = KH > 32 ? 512 : 1024, NW = NT / 64;  // deeper k needs more registers per lane
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    for (int j = 0; j < Bt.n; ++j) {
+        const GemmJob &J = Bt.j[j];
+        const int K = J.K1 + J.K2, ld = Pa.lds_ld[j], q4 = ld / 4;
+        float *dst = g_lds + Pa.lds_off[j];
+        for (int idx = tid; idx < 2 * KH * q4; idx += NT) {
+            const int k = idx / q4, c = (idx % q4) * 4;
+            const float4 v = (k < K && c < J.ldb) ? ld4(J.B + (size_t)k * J.ldb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(dst + k * ld + c) = v;
+        }
+    }
+    __syncthreads();
+    const int n_tiles = (int)((n_rows + 31) / 32);
+    const int stride = gridDim.x * NW;
+    for (int item = blockIdx.x * NW + (tid >> 6); item < Pa.n_items; item += stride) {
+        int j = 0;
+        while (j + 1 < Bt.n && item >= Pa.item_start[j + 1]) ++j;
+        const GemmJob &J = Bt.j[j];
+        const int local = item - Pa.item_start[j];
+        const int tile = local % n_tiles, grp = local / n_tiles;  // consecutive waves -> consecutive row tiles
+        const int64_t row0 = (int64_t)tile * 32, grow = row0 + r;
+        const bool rv = grow < n_rows;
+        const int64_t srow = rv ? (rows ? (int64_t)rows[grow] : grow) : 0;
+        float a[KH];
+        load_a<KH>(J, srow, rv, h * KH, a);
+        const int ld = Pa.lds_ld[j];
+        const float *bimg = g_lds + Pa.lds_off[j] + (h * KH) * ld + r;
+        const int nct = (J.n_out + 31) / 32;
+        const int ct_end = min(nct, (grp + 1) * kColGroup);
+        for (int ct = grp * kColGroup; ct < ct_end; ++ct) {
+            const int col0 = ct * 32, c = col0 + r;
+            float b[KH];
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) b[kk] = bimg[kk * ld + col0];
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+            if (c >= J.n_out) continue;
+            float *dst = nullptr;
+            int ldo = 0, relu = 0;
+            for (int sg = 0; sg < J.n_seg; ++sg)
+                if (c >= J.seg[sg].c0 && c < J.seg[sg].c1) {
+                    dst = J.seg[sg].dst + (c - J.seg[sg].c0);
+                    ldo = J.seg[sg].ld;
+                    relu = J.seg[sg].relu;
+                }
+            if (!dst) continue;
+            const float bias = J.bias ? J.bias[c] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t g = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (g >= n_rows) continue;
+                const int64_t orow = rows ? (int64_t)rows[g] : g;
+                float v = acc[reg] + bias;
+                if (relu) v = fmaxf(v, 0.f);
+                dst[orow * ldo] = v;
+            }
+        }
+    }
+}
+
 struct PackLaunch {
     int n;
     PackJob j[24];
@@ -188,38 +277,122 @@ static int check_job(const GemmJob &job) {
     return PEA_OK;
 }
 
-// Jobs of one call share the row set; jobs with the same k-depth class go out as one launch (grid.y = job).
-int launch_gemm_batch(const GemmJob *jobs, int n_jobs, const int *rows, int64_t n_rows, hipStream_t stream) {
-    if (n_rows <= 0 || n_jobs <= 0) return PEA_OK;
-    for (int i = 0; i < n_jobs; ++i) PEA_TRY(check_job(jobs[i]));
+constexpr size_t kLdsBudget = 160 * 1024 - 1024;  // dynamic LDS a workgroup may claim (one workgroup per CU)
+
+template <int KH>
+int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double bytes, hipStream_t stream) {
+    PersistArgs Pa;
+    const int n_tiles = (int)((n_rows + 31) / 32);
+    int off = 0, items = 0;
+    for (int j = 0; j < Bt.n; ++j) {
+        const int nct = (Bt.j[j].n_out + 31) / 32;
+        Pa.lds_ld[j] = nct * 32;
+        Pa.lds_off[j] = off;
+        off += 2 * KH * Pa.lds_ld[j];
+        Pa.item_start[j] = items;
+        items += n_tiles * ((nct + kColGroup - 1) / kColGroup);
+    }
+    Pa.item_start[Bt.n] = items;
+    Pa.n_items = items;
+    const size_t lds = (size_t)off * sizeof(float);
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        PEA_HIP(hipGetDevice(&dev));
+        PEA_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_persist_kernel<KH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    const int per_cu = lds * 2 <= kLdsBudget ? 2 : 1;  // two workgroups share a CU when their B images both fit
+    constexpr int NT = KH > 32 ? 512 : 1024;
+    const int grid = std::min(n_cu * per_cu, (items + NT / 64 - 1) / (NT / 64));
+    ProfScope ps(Bt.n == 1 ? "gemm_mfma_shared" : "gemm_mfma_batch", stream, bytes);
+    hipLaunchKernelGGL(gemm_persist_kernel<KH>, dim3((unsigned)grid), dim3(NT), lds, stream, Bt, Pa, rows, n_rows);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+// Jobs of one call share the row set; jobs with the same k-depth class go out as one launch.  A job whose B does
+// not fit the LDS budget is cut into column chunks; k deeper than 128 falls back to the staged kernel.
+int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, int64_t n_rows, hipStream_t stream) {
+    if (n_rows <= 0 || n_jobs_in <= 0) return PEA_OK;
+    std::vector<GemmJob> jobs;
+    for (int i = 0; i < n_jobs_in; ++i) {
+        PEA_TRY(check_job(jobs_in[i]));
+        const GemmJob &J = jobs_in[i];
+        const int K = J.K1 + J.K2;
+        const int KH = K <= 32 ? 16 : K <= 64 ? 32 : 64;
+        const int max_cols = (int)(kLdsBudget / sizeof(float) / (size_t)(2 * KH)) / 32 * 32;
+        if (K > 128 || J.n_out <= max_cols) {
+            jobs.push_back(J);
+            continue;
+        }
+        for (int c0 = 0; c0 < J.n_out; c0 += max_cols) {  // column chunks of an oversize job
+            GemmJob C = J;
+            const int c1 = std::min(J.n_out, c0 + max_cols);
+            C.B = J.B + c0;
+            C.n_out = c1 - c0;
+            C.bias = J.bias ? J.bias + c0 : nullptr;
+            C.n_seg = 0;
+            for (int sg = 0; sg < J.n_seg; ++sg) {
+                const int a0 = std::max(J.seg[sg].c0, c0), a1 = std::min(J.seg[sg].c1, c1);
+                if (a1 <= a0) continue;
+                GemmSegment S = J.seg[sg];
+                S.dst = J.seg[sg].dst + (a0 - J.seg[sg].c0);
+                S.c0 = a0 - c0;
+                S.c1 = a1 - c0;
+                C.seg[C.n_seg++] = S;
+            }
+            if (C.n_seg) jobs.push_back(C);
+        }
+    }
+    const int n_jobs = (int)jobs.size();
     const int classes[3] = {16, 32, 64};
     for (int ci = 0; ci < 3; ++ci) {
-        GemmBatch Bt;
-        Bt.n = 0;
-        double bytes = 0.0;
-        auto flush = [&]() -> int {
-            if (Bt.n == 0) return PEA_OK;
-            dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)Bt.n);
-            ProfScope ps(Bt.n == 1 ? "gemm_mfma_shared" : "gemm_mfma_batch", stream, bytes);
-            switch (classes[ci]) {
-                case 16: hipLaunchKernelGGL(gemm_mfma_kernel<16>, grid, dim3(256), 0, stream, Bt, rows, n_rows); break;
-                case 32: hipLaunchKernelGGL(gemm_mfma_kernel<32>, grid, dim3(256), 0, stream, Bt, rows, n_rows); break;
-                default: hipLaunchKernelGGL(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows); break;
-            }
-            PEA_HIP(hipGetLastError());
+        for (int deep = 0; deep < 2; ++deep) {  // deep: K > 2*KH, staged kernel
+            GemmBatch Bt;
             Bt.n = 0;
-            bytes = 0.0;
-            return PEA_OK;
-        };
-        for (int i = 0; i < n_jobs; ++i) {
-            const int K = jobs[i].K1 + jobs[i].K2;
-            const int cls = K <= 32 ? 16 : K <= 64 ? 32 : 64;  // k per lane half; deeper K loops in chunks of 128
-            if (cls != classes[ci]) continue;
-            Bt.j[Bt.n++] = jobs[i];
-            bytes += 4.0 * (double)n_rows * (K + jobs[i].n_out);
-            if (Bt.n == kMaxBatch) PEA_TRY(flush());
+            double bytes = 0.0;
+            size_t lds = 0;
+            auto flush = [&]() -> int {
+                if (Bt.n == 0) return PEA_OK;
+                int rc = PEA_OK;
+                if (!deep) {
+                    switch (classes[ci]) {
+                        case 16: rc = launch_persist<16>(Bt, rows, n_rows, bytes, stream); break;
+                        case 32: rc = launch_persist<32>(Bt, rows, n_rows, bytes, stream); break;
+                        default: rc = launch_persist<64>(Bt, rows, n_rows, bytes, stream); break;
+                    }
+                } else {
+                    dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)Bt.n);
+                    ProfScope ps("gemm_mfma_deep", stream, bytes);
+                    hipLaunchKernelGGL(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows);
+                    if (hipGetLastError() != hipSuccess) rc = PEA_ERR_HIP;
+                }
+                Bt.n = 0;
+                bytes = 0.0;
+                lds = 0;
+                return rc;
+            };
+            for (int i = 0; i < n_jobs; ++i) {
+                const int K = jobs[i].K1 + jobs[i].K2;
+                const int cls = K <= 32 ? 16 : K <= 64 ? 32 : 64;
+                if (cls != classes[ci] || (K > 128) != (deep == 1)) continue;
+                const size_t need = (size_t)2 * cls * ((jobs[i].n_out + 31) / 32 * 32) * sizeof(float);
+                if (!deep && Bt.n > 0 && lds + need > kLdsBudget) PEA_TRY(flush());
+                Bt.j[Bt.n++] = jobs[i];
+                lds += need;
+                bytes += 4.0 * (double)n_rows * (K + jobs[i].n_out);
+                if (Bt.n == kMaxBatch) PEA_TRY(flush());
+            }
+            PEA_TRY(flush());
         }
-        PEA_TRY(flush());
     }
     return PEA_OK;
 }
