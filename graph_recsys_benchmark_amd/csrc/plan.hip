@@ -47,10 +47,20 @@ __global__ void keys_with_slice(int64_t E, int64_t N, const int *__restrict__ ke
 }
 
 __global__ void src_range(int64_t E, int64_t N, const int *__restrict__ keys, const int *__restrict__ vals, int *mn, int *mx) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E || keys[e] >= (int)N) return;
-    atomicMin(mn, vals[e]);
-    atomicMax(mx, vals[e]);
+    int lo = INT32_MAX, hi = -1;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
+        if (keys[e] < (int)N) {
+            lo = min(lo, vals[e]);
+            hi = max(hi, vals[e]);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0 && hi >= 0) {  // one atomic pair per wave
+        atomicMin(mn, lo);
+        atomicMax(mx, hi);
+    }
 }
 
 __global__ void rowptr_from_sorted64(int64_t E, int64_t N, int S, const unsigned long long *__restrict__ keys,
@@ -170,7 +180,7 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
             int h_mm[2] = {INT32_MAX, -1}, *mm = nullptr;
             PEA_HIP_C(hipMalloc((void **)&mm, 2 * sizeof(int)));
             PEA_HIP_C(hipMemcpyAsync(mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(src_range, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, E, N, keys_in, vals_in, mm, mm + 1);
+            hipLaunchKernelGGL(src_range, dim3((unsigned)std::min<int64_t>((E + 255) / 256, 2048)), dim3(256), 0, stream, E, N, keys_in, vals_in, mm, mm + 1);
             PEA_HIP_C(hipMemcpyAsync(h_mm, mm, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
             PEA_HIP_C(hipStreamSynchronize(stream));
             (void)hipFree(mm);

@@ -13,13 +13,13 @@ import sys
 
 
 def short(name):
-    m = re.search(r'(agg_\w+_kernel)<(\d+), *(\d+)>', name)
+    m = re.search(r'(agg_\w+_kernel)<(\d+), *(\d+)(?:, *\d+)?>', name)
     if m:
         mode = {'0': 'gat', '1': 'gcn', '2': 'mean'}[m.group(3)]
         return '%s_g%s_%s' % (m.group(1).replace('_kernel', ''), m.group(2), mode)
-    m = re.search(r'(gemm_mfma_kernel)<(\d+)>', name)
+    m = re.search(r'(gemm_mfma|gemm_persist)_kernel<(\d+)>', name)
     if m:
-        return 'gemm_mfma_k%s' % m.group(2)
+        return '%s_k%s' % (m.group(1), m.group(2))
     m = re.search(r'pea::\(anonymous namespace\)::(\w+)', name)
     return m.group(1) if m else name[:48]
 
