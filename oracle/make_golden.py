@@ -240,6 +240,104 @@ def make_checkpoint_manifest():
     print('checkpoint_manifest.json', {k: len(v['keys']) for k, v in man.items()})
 
 
+class _FakeDataset:
+    """The attributes the reference's sampling / evaluation code reads from a dataset object
+    (datasets/movielens.py:879-997, solvers.py:21-31,50-54), filled from a tiny synthetic HIN."""
+
+    def __init__(self, seed, n_user=40, n_item=70, e=600):
+        rng = np.random.default_rng(seed)
+        self.type_accs = {'uid': 0, 'iid': n_user}
+        self.num_uids, self.num_iids = n_user, n_item
+        u = rng.integers(0, n_user, size=e)
+        i = n_user + rng.integers(0, n_item, size=e)
+        pairs = np.unique(np.stack([u, i]), axis=1)
+        self.edge_index_nps = {'user2item': pairs.astype(np.float64)}
+        seen = {int(x): set() for x in range(n_user)}
+        for a, b in pairs.T:
+            seen[int(a)].add(int(b))
+        self.test_pos_unid_inid_map, self.neg_unid_inid_map = {}, {}
+        for x in range(n_user):
+            unseen = [j for j in range(n_user, n_user + n_item) if j not in seen[x]]
+            k = int(rng.integers(0, len(unseen)))
+            self.test_pos_unid_inid_map[x] = [unseen[k]]           # leave-one-out positive
+            self.neg_unid_inid_map[x] = unseen[:k] + unseen[k + 1:]
+        self.cf_loss_type, self.entity_aware = 'BPR', False
+        self.num_negative_samples = 4
+
+
+def load_reference_sampling_and_solver(mods):
+    """datasets/movielens.py (cf_negative_sampling) and solvers.py (generate_candidates, metrics) loaded file-by-file;
+    the only foreign names they need at import time are torch_geometric.data.{download_url,extract_zip} (never called)
+    and the parser entry points (never called)."""
+    tgd = types.ModuleType('torch_geometric.data')
+    tgd.download_url = tgd.extract_zip = lambda *a, **k: (_ for _ in ()).throw(RuntimeError('offline'))
+    sys.modules['torch_geometric.data'] = tgd
+    sys.modules['torch_geometric'].data = tgd
+    par = types.ModuleType('graph_recsys_benchmark.parser')
+    par.parse_ml25m = par.parse_mlsmall = par.parse_yelp = None
+    sys.modules['graph_recsys_benchmark.parser'] = par
+    ds = types.ModuleType('graph_recsys_benchmark.datasets')
+    ds.__path__ = [os.path.join(REF, 'graph_recsys_benchmark', 'datasets')]
+    sys.modules['graph_recsys_benchmark.datasets'] = ds
+    for alias, typ in (('long', np.int64), ('str', str), ('int', int)):
+        if not hasattr(np, alias):
+            setattr(np, alias, typ)          # aliases removed in numpy 1.24 (datasets/movielens.py:35-54,935)
+    ml = importlib.import_module('graph_recsys_benchmark.datasets.movielens')
+    up = sys.modules['graph_recsys_benchmark.utils']
+    up.hit, up.ndcg, up.auc = mods['rec_utils'].hit, mods['rec_utils'].ndcg, mods['rec_utils'].auc
+    solvers = importlib.import_module('graph_recsys_benchmark.solvers')
+    return ml, solvers
+
+
+def make_sampling_and_metrics(mods):
+    ml, solvers = load_reference_sampling_and_solver(mods)
+    out = {}
+    # --- BPR negative sampling, both strategies (datasets/movielens.py:920-940,994-997)
+    for strategy in ('random', 'unseen'):
+        fake = _FakeDataset(11)
+        fake.sampling_strategy = strategy
+        random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
+        ml.MovieLens.cf_negative_sampling(fake)
+        out['train_data_' + strategy] = fake.train_data.numpy()
+    # --- evaluation loop (solvers.py:33-104) on a CPU reference model
+    fake = _FakeDataset(12)
+    n = fake.num_uids + fake.num_iids + 6
+    u2i = torch.from_numpy(fake.edge_index_nps['user2item']).long()
+    attr = torch.stack([torch.randint(n - 6, n, (80,), generator=torch.Generator().manual_seed(3)),
+                        fake.num_uids + torch.randint(0, fake.num_iids, (80,), generator=torch.Generator().manual_seed(4))])
+    mpl = [[u2i, torch.flip(u2i, dims=[0])], [torch.flip(u2i, dims=[0]), u2i], [attr, torch.flip(u2i, dims=[0])]]
+
+    class PEAModel(mods['peagat'].PEAGATRecsysModel):
+        def update_graph_input(self, dataset):
+            return mpl
+
+    torch.manual_seed(5)
+    model = PEAModel(entity_aware=False, entity_aware_coff=0.1, meta_path_steps=[2, 2, 2], if_use_features=False,
+                     channel_aggr='att', dataset={'num_nodes': n}, num_nodes=n, emb_dim=32, hidden_size=24, repr_dim=16,
+                     num_heads=1, dropout=0)
+    with torch.no_grad():
+        for pname, p in model.named_parameters():
+            if pname.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+            elif pname != 'x':
+                p.mul_(2.0)
+    solver = solvers.BaseSolver(PEAModel, {}, {'model_type': 'Graph'}, {'num_neg_candidates': 99, 'device': 'cpu'})
+    model.eval()
+    np.random.seed(2021)
+    with torch.no_grad():
+        hr, nd, auc, loss = solver.metrics(1, 1, model, fake)
+    out.update(metrics_HR=hr, metrics_NDCG=nd, metrics_AUC=auc, metrics_loss=loss)
+    for k, v in model.state_dict().items():
+        out['metrics_param/' + k] = v.numpy()
+    for p, eil in enumerate(mpl):
+        for s_, ei in enumerate(eil):
+            out['metrics_edge/%d/%d' % (p, s_)] = ei.numpy()
+    out['metrics_num_nodes'] = np.int64(n)
+    np.savez_compressed(os.path.join(OUT, 'sampling_metrics.npz'), **out)
+    print('sampling_metrics.npz', {k: np.asarray(v).shape for k, v in out.items() if not k.startswith('metrics_param') and not k.startswith('metrics_edge')},
+          'HR@10 %.4f' % hr[5])
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     mods = load_reference_models()
@@ -255,3 +353,4 @@ if __name__ == '__main__':
     make_rec_utils(mods)
     make_rng_streams()
     make_checkpoint_manifest()
+    make_sampling_and_metrics(mods)
