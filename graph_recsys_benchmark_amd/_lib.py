@@ -28,7 +28,8 @@ class ModelDesc(C.Structure):
     _fields_ = [('kind', C.c_int), ('num_channels', C.c_int), ('steps', C.POINTER(C.c_int)),
                 ('relation_of', C.POINTER(C.c_int)), ('emb_dim', C.c_int), ('hidden_size', C.c_int),
                 ('repr_dim', C.c_int), ('heads', C.c_int), ('fuse_mode', C.c_int),
-                ('gcn_deg_from_col', C.c_int), ('negative_slope', C.c_float)]
+                ('gcn_deg_from_col', C.c_int), ('negative_slope', C.c_float), ('enable_backward', C.c_int),
+                ('reverse_of', C.POINTER(C.c_int))]
 
 
 class ExchangeDesc(C.Structure):
@@ -58,6 +59,9 @@ SIGNATURES = {
     'pea_model_forward_stage': (_int, [_vp, _int, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
     'pea_model_num_exchanges': (_int, [_vp, _int]),
     'pea_model_exchange_desc': (_int, [_vp, _int, _int, C.POINTER(ExchangeDesc)]),
+    'pea_model_forward_train': (_int, [_vp, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
+    'pea_model_backward_level': (_int, [_vp, _int, _int, _vp, _sz, _vp]),
+    'pea_model_describe': (_int, [_vp, C.POINTER(_i64), _int, C.POINTER(_int)]),
     'pea_model_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
     'pea_conv_workspace_bytes': (_sz, [_vp, _int, _int, _int, _int, _int]),
     'pea_gat_conv': (_int, [_vp, _int, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, C.c_float, _int, _vp, _i64, _vp, _sz, _vp]),

@@ -1,0 +1,169 @@
+"""loss.backward() through the HIP conv stack (reference training step solvers.py:213-216).
+
+    PEAStackFunction.apply(engine, x, *conv parameters) -> stack [N, P, R]   (the per-metapath representations that
+                                                                             models/base.py:193-196 concatenates)
+
+forward  = pea_model_forward_train (all P x S conv layers, softmax statistics kept in the workspace)
+backward = per level, last to first:
+             pea_model_backward_level  -- the sparse half in HIP: relu masks, bias / attention-vector gradient
+                                          reductions, gradient gathers over the reversed relations (csrc/agg_bwd.hip)
+             torch.mm on workspace views -- the dense half: dW = In^T dT, dIn = dT W (plain rocBLAS GEMMs)
+The fusion and the BPR scorer on top of `stack` are differentiated by torch autograd (models/base.py here).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import PARAM_SLOTS
+
+
+class _Layout:
+    """Parsed pea_model_describe output (float offsets from the 256-byte aligned workspace base)."""
+
+    def __init__(self, engine):
+        lib = _lib.load()
+        need = C.c_int()
+        _lib.check(lib.pea_model_describe(engine._h, None, 0, C.byref(need)))
+        buf = (C.c_int64 * need.value)()
+        _lib.check(lib.pea_model_describe(engine._h, buf, need.value, C.byref(need)))
+        v = list(buf)
+        self.n_levels, self.ld_x, self.off_x, self.off_dx, self.off_gpack, self.pack_floats = v[:6]
+        i = 6
+        self.levels = []
+        for _ in range(self.n_levels):
+            names = ('ld_t', 'ld_o', 'off_t', 'off_o', 'off_dt', 'off_do', 'off_side', 'bias_off', 'att_src_off',
+                     'att_dst_off', 'n_units')
+            lv = dict(zip(names, v[i:i + 11]))
+            i += 11
+            units = []
+            for _ in range(lv['n_units']):
+                un = ('p', 's', 'rel', 'in_w', 'heads', 'F', 'HF', 'last', 'in_col', 't_col', 'o_col', 'b_off', 'ldb',
+                      'bias_off')
+                units.append(dict(zip(un, v[i:i + 14])))
+                i += 14
+            lv['units'] = units
+            self.levels.append(lv)
+
+
+def _view(wsf, off, n, ld):
+    return wsf[off:off + n * ld].view(n, ld)
+
+
+def backward_conv_stack(engine, d_stack, x, layer_params):
+    """Gradients of sum(stack * d_stack) wrt x and every conv parameter.  Returns (dx, [tuple per layer])."""
+    lib = _lib.load()
+    if not engine.enable_backward:
+        raise RuntimeError('engine was built without enable_backward')
+    lay = getattr(engine, '_layout', None)
+    if lay is None:
+        lay = engine._layout = _Layout(engine)
+    kind, n, wsf = engine.kind, engine.plan.num_nodes, engine._wsf
+    slots = PARAM_SLOTS[kind]
+    first = [0]
+    for s_ in engine.steps:
+        first.append(first[-1] + s_)
+    grads = [[None] * len(slots) for _ in range(engine.n_layers)]
+    dx = torch.zeros_like(x)
+    gpack = wsf[lay.off_gpack:lay.off_gpack + lay.pack_floats]
+    # 1. gradient of the last-layer outputs, internal column order
+    dX = _view(wsf, lay.off_dx, n, lay.ld_x)
+    for lv in lay.levels:
+        for u in lv['units']:
+            if u['last']:
+                dX[:, u['o_col']:u['o_col'] + u['HF']] = d_stack[:, u['p'], :]
+    stream = _lib.current_stream()
+
+    def level_call(level, phase):
+        _lib.check(lib.pea_model_backward_level(engine._h, level, phase, _lib.ptr(engine._ws), engine.workspace_bytes,
+                                                stream))
+
+    for s in range(lay.n_levels - 1, -1, -1):
+        lv = lay.levels[s]
+        T = _view(wsf, lv['off_t'], n, lv['ld_t'])
+        dT = _view(wsf, lv['off_dt'], n, lv['ld_t'])
+        dO = _view(wsf, lv['off_do'], n, max(lv['ld_o'], 4))
+        prev = lay.levels[s - 1] if s > 0 else None
+        In_all = x if s == 0 else _view(wsf, prev['off_o'], n, prev['ld_o'])
+        dIn_all = None if s == 0 else _view(wsf, prev['off_do'], n, max(prev['ld_o'], 4))
+        if kind == 'sage':
+            level_call(s, 0)
+            dT.zero_()
+            for u in lv['units']:
+                li = first[u['p']] + u['s']
+                w_rel, _b, w_root = layer_params[li]
+                G = (dX if u['last'] else dO)[:, u['o_col']:u['o_col'] + u['HF']]
+                M = T[:, u['t_col']:u['t_col'] + u['in_w']]
+                In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
+                grads[li][0] = G.t() @ M
+                grads[li][2] = G.t() @ In
+                grads[li][1] = gpack[u['bias_off']:u['bias_off'] + u['HF']].clone()
+                dT[:, u['t_col']:u['t_col'] + u['in_w']] += G @ w_rel          # level 0: channels of one relation share M
+                direct = G @ w_root
+                if s == 0:
+                    dx += direct
+                else:
+                    dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = direct
+            level_call(s, 1)
+            dagg = _view(wsf, lv['off_side'], n, lv['ld_t'])
+            done = set()
+            for u in lv['units']:
+                if s == 0:
+                    if u['t_col'] not in done:
+                        dx += dagg[:, u['t_col']:u['t_col'] + u['in_w']]
+                        done.add(u['t_col'])
+                else:
+                    dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] += dagg[:, u['t_col']:u['t_col'] + u['in_w']]
+            continue
+        level_call(s, 0)
+        for u in lv['units']:
+            li = first[u['p']] + u['s']
+            dTu = dT[:, u['t_col']:u['t_col'] + u['HF']]
+            In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
+            if kind == 'gat':
+                w = layer_params[li][0]                                     # lin.weight [HF, in]
+                grads[li][0] = dTu.t() @ In
+                dIn = dTu @ w
+                shape = layer_params[li][1].shape
+                grads[li][1] = gpack[lv['att_dst_off'] + u['t_col']:lv['att_dst_off'] + u['t_col'] + u['HF']].clone().view(shape)
+                grads[li][2] = gpack[lv['att_src_off'] + u['t_col']:lv['att_src_off'] + u['t_col'] + u['HF']].clone().view(shape)
+                grads[li][3] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
+            else:
+                w = layer_params[li][0]                                     # weight [in, F]
+                grads[li][0] = In.t() @ dTu
+                dIn = dTu @ w.t()
+                grads[li][1] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
+            if s == 0:
+                dx += dIn
+            else:
+                dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = dIn
+    return dx, grads
+
+
+class PEAStackFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, x, n_slots, *flat):
+        layer_params = [tuple(flat[i:i + n_slots]) for i in range(0, len(flat), n_slots)]
+        _, stack = engine.forward(layer_params, x, att=torch.zeros(engine.P, engine.repr_dim, device=x.device),
+                                  want_stack=True, train=True)
+        ctx.engine, ctx.n_slots = engine, n_slots
+        ctx.save_for_backward(x, *[t for t in flat if t is not None])
+        ctx.present = [t is not None for t in flat]
+        return stack
+
+    @staticmethod
+    def backward(ctx, d_stack):
+        saved = list(ctx.saved_tensors)
+        x, rest = saved[0], saved[1:]
+        flat, it = [], iter(rest)
+        for p in ctx.present:
+            flat.append(next(it) if p else None)
+        n_slots = ctx.n_slots
+        layer_params = [tuple(flat[i:i + n_slots]) for i in range(0, len(flat), n_slots)]
+        with torch.no_grad():
+            dx, grads = backward_conv_stack(ctx.engine, d_stack.contiguous(), x, layer_params)
+        out = []
+        for lp, g in zip(layer_params, grads):
+            for t, gt in zip(lp, g):
+                out.append(None if t is None else gt.reshape(t.shape))
+        return (None, dx, None, *out)

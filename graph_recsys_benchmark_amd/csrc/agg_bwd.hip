@@ -1,0 +1,397 @@
+// Backward of the GAT aggregation for gfx950 (training; SURVEY.md section 8f rank 1: loss.backward() at reference
+// solvers.py:215 runs autograd through GATConv's index_select / softmax / scatter).  Two gather passes, no atomics:
+//
+//   forward, per head:  z_ij = a_src_j + a_dst_i,  e_ij = leaky_relu(z_ij),  alpha_ij = exp(e_ij - m_i) / (S_i + 1e-16),
+//                       out_i = sum_j alpha_ij T_j + b        (a_src_j = att_j . T_j,  a_dst_i = att_i . T_i)
+//   given g_i = dL/d out_i:   c_i = g_i . (out_i - b)                      (= sum_j alpha_ij  g_i . T_j)
+//                             d e_ij = alpha_ij (g_i . T_j - c_i),  d z_ij = d e_ij * leaky'(z_ij)
+//   D pass (destination rows, forward CSR, gathers T_j):   d a_dst_i = sum_j d z_ij   (+ the side record
+//                             [a_dst_i, m_i, 1/(S_i+eps), c_i] the S pass gathers)
+//   S pass (source rows, REVERSED relation, gathers g_i):  d a_src_j = sum_i d z_ij
+//                             dT_j = sum_i alpha_ij g_i + att_j d a_src_j + att_i d a_dst_j
+// The softmax statistics (m_i in the log2 domain, S_i) were saved by the forward (AggGroup::stats); logits are
+// recomputed from the rows exactly as in agg.hip (packed att vectors carry log2(e); natural-unit gradients get ln 2).
+// Same work decomposition as the forward: short rows per lane subgroup, long rows / hub chunks per wave, hub chunks
+// folded in chunk order by a merge kernel -> bitwise reproducible gradients.
+#include "agg_common.h"
+
+namespace pea {
+namespace {
+
+constexpr float kLn2 = 0.69314718055994530942f;
+
+struct RowD {  // row-local state of the D pass
+    float4 att_s, g, hself;
+    float a_d, m, inv_s, c;
+};
+
+template <int F4T>
+__device__ __forceinline__ RowD load_row_d(const AggGroup &P, int row, int c4, int lane, int pos, int F4, bool pow2) {
+    RowD r;
+    r.att_s = ld4(P.att_src + c4);
+    r.hself = ld4(row_at(P.feat_self + c4, row, P.ld_self));
+    r.a_d = head_sum<F4T>(dot4(r.hself, ld4(P.att_dst + c4)), lane, pos, F4, pow2);
+    r.g = ld4(row_at(P.g_self + c4, row, P.ld_g));
+    float4 o = ld4(row_at(P.o_self + c4, row, P.ld_g));
+    if (P.bias) {
+        const float4 b = ld4(P.bias + c4);
+        o = make_float4(o.x - b.x, o.y - b.y, o.z - b.z, o.w - b.w);
+    }
+    r.c = head_sum<F4T>(dot4(r.g, o), lane, pos, F4, pow2);
+    const float *sp = P.stats + (size_t)row * P.ld_stats + 2 * (c4 / P.F);
+    r.m = sp[0];
+    r.inv_s = 1.0f / (sp[1] + 1e-16f);
+    return r;
+}
+
+// d z of one edge as seen from the destination row (h = gathered T_j)
+template <int F4T>
+__device__ __forceinline__ float dz_edge_d(const AggGroup &P, const RowD &r, float4 h, int lane, int pos, int F4, bool pow2) {
+    const float zl = head_sum<F4T>(dot4(h, r.att_s), lane, pos, F4, pow2) + r.a_d;
+    const float alpha = __builtin_amdgcn_exp2f(leaky(zl, P.neg_slope) - r.m) * r.inv_s;
+    const float dal = head_sum<F4T>(dot4(h, r.g), lane, pos, F4, pow2);
+    return alpha * (dal - r.c) * (zl > 0.f ? 1.f : P.neg_slope);
+}
+
+__device__ __forceinline__ void finish_d(const AggGroup &P, const RowD &r, int row, int c4, float dsum) {
+    if (c4 % P.F != 0) return;
+    const int k = c4 / P.F;
+    P.ksum[(size_t)row * P.ld_k + k] = dsum;
+    st4(P.side_out + (size_t)row * P.ld_side + 4 * k, make_float4(r.a_d, r.m, r.inv_s, r.c));
+}
+
+struct RowS {  // row-local state of the S pass
+    float4 att_s, t;
+    float a_s;
+};
+
+template <int F4T>
+__device__ __forceinline__ RowS load_row_s(const AggGroup &P, int row, int c4, int lane, int pos, int F4, bool pow2) {
+    RowS r;
+    r.att_s = ld4(P.att_src + c4);
+    r.t = ld4(row_at(P.feat_self + c4, row, P.ld_self));
+    r.a_s = head_sum<F4T>(dot4(r.t, r.att_s), lane, pos, F4, pow2);
+    return r;
+}
+
+// one out-edge as seen from the source row: g = gathered output-gradient row of the destination, sd = its side record
+template <int F4T>
+__device__ __forceinline__ void edge_s(const AggGroup &P, const RowS &r, float4 g, float4 sd, bool ok, int lane, int pos,
+                                       int F4, bool pow2, float4 &acc, float &dzs) {
+    const float zl = r.a_s + sd.x;
+    const float alpha = __builtin_amdgcn_exp2f(leaky(zl, P.neg_slope) - sd.y) * sd.z;
+    const float dal = head_sum<F4T>(dot4(g, r.t), lane, pos, F4, pow2);
+    const float dz = alpha * (dal - sd.w) * (zl > 0.f ? 1.f : P.neg_slope);
+    if (ok) {
+        acc = fma4(alpha, g, acc);
+        dzs += dz;
+    }
+}
+
+__device__ __forceinline__ void finish_s(const AggGroup &P, const RowS &r, int row, int c4, float4 acc, float dzs) {
+    const int k = c4 / P.F;
+    const float dad = P.da_dst[(size_t)row * P.ld_k + k];
+    const float4 at_d = ld4(P.att_dst + c4);
+    const float ws = kLn2 * dzs, wd = kLn2 * dad;  // the packed att vectors carry log2(e)
+    float4 o;
+    o.x = acc.x + ws * r.att_s.x + wd * at_d.x;
+    o.y = acc.y + ws * r.att_s.y + wd * at_d.y;
+    o.z = acc.z + ws * r.att_s.z + wd * at_d.z;
+    o.w = acc.w + ws * r.att_s.w + wd * at_d.w;
+    st4(P.out + (size_t)row * P.ld_out + c4, o);
+    if (c4 % P.F == 0) P.ksum[(size_t)row * P.ld_k + k] = dzs;
+}
+
+// ------------------------------------------------------------------------------------------------ short rows
+template <int G, int MODE, int F4T>
+__global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / G) + (int)threadIdx.x / G;
+    const int sl = (int)threadIdx.x % G, lane = (int)threadIdx.x % kWave;
+    const bool valid = item < P.n_short;
+    const int row = valid ? P.short_rows[item] : 0;
+    const bool active = valid && sl * 4 < P.W;
+    const int c4 = active ? sl * 4 : 0;
+    const int beg = P.rowptr[row];
+    const int end = valid ? P.rowptr[row + 1] : beg;
+    const int F4 = P.F / 4, pos = sl % F4;
+    const bool pow2 = (F4 & (F4 - 1)) == 0;
+    const int k = c4 / P.F;
+    int len = end - beg;
+    for (int off = G; off < kWave; off <<= 1) len = max(len, __shfl_xor(len, off));  // head sums are cross-lane
+    if (MODE == AGG_GAT_BWD_D) {
+        const RowD r = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
+        float dsum = 0.f;
+        for (int t = 0; t < len; ++t) {
+            const bool ok = beg + t < end;
+            const int j = ok ? P.col[beg + t] : 0;
+            const float dz = dz_edge_d<F4T>(P, r, ld4(row_at(P.feat + c4, j, P.ld_feat)), lane, pos, F4, pow2);
+            if (ok) dsum += dz;
+        }
+        if (P.self_loop) dsum += dz_edge_d<F4T>(P, r, r.hself, lane, pos, F4, pow2);
+        if (active) finish_d(P, r, row, c4, dsum);
+    } else {
+        const RowS r = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dzs = 0.f;
+        for (int t = 0; t < len; ++t) {
+            const bool ok = beg + t < end;
+            const int i = ok ? P.col[beg + t] : 0;
+            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, i, P.ld_feat)), ld4(row_at(P.side + 4 * k, i, P.ld_side)), ok, lane, pos,
+                        F4, pow2, acc, dzs);
+        }
+        if (P.self_loop)
+            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), true, lane,
+                        pos, F4, pow2, acc, dzs);
+        if (active) finish_s(P, r, row, c4, acc, dzs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ long rows / hub chunks
+template <int G, int MODE, int F4T>
+__global__ __launch_bounds__(kBlock) void bwd_long_kernel(const AggLaunch L) {
+    constexpr int NSG = kWave / G, U = 4;
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int lane = (int)threadIdx.x % kWave;
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + (int)threadIdx.x / kWave;
+    if (item >= P.n_long) return;
+    const LongItem it = P.long_items[item];
+    if (it.slot == -2) return;
+    const int sub = lane / G, sl = lane % G;
+    const bool active = sl * 4 < P.W;
+    const int c4 = active ? sl * 4 : 0;
+    const int row = it.row;
+    const int F4 = P.F / 4, pos = sl % F4;
+    const bool pow2 = (F4 & (F4 - 1)) == 0;
+    const int k = c4 / P.F, nk = P.W / P.F;
+    RowD rd;
+    RowS rs;
+    if (MODE == AGG_GAT_BWD_D) rd = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
+    else rs = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dsum = 0.f;
+    int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
+    for (int base = it.beg; base < it.end; base += kWave) {
+        const int nxt = base + kWave + lane;
+        const int src_next = nxt < it.end ? P.col[nxt] : -1;
+        const int cnt = min(kWave, it.end - base);
+        for (int t = 0; t < cnt; t += NSG * U) {
+            int jj[U];
+            bool ok[U];
+            float4 h[U], sd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = t + u * NSG + sub;
+                const int j = __shfl(src, idx & (kWave - 1));
+                ok[u] = idx < cnt && j >= 0;
+                jj[u] = ok[u] ? j : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                h[u] = ld4(row_at(P.feat + c4, jj[u], P.ld_feat));
+                if (MODE == AGG_GAT_BWD_S) sd[u] = ld4(row_at(P.side + 4 * k, jj[u], P.ld_side));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (MODE == AGG_GAT_BWD_D) {
+                    const float dz = dz_edge_d<F4T>(P, rd, h[u], lane, pos, F4, pow2);
+                    if (ok[u]) dsum += dz;
+                } else {
+                    edge_s<F4T>(P, rs, h[u], sd[u], ok[u], lane, pos, F4, pow2, acc, dsum);
+                }
+            }
+        }
+        src = src_next;
+    }
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) {
+        dsum += __shfl_xor(dsum, off);
+        if (MODE == AGG_GAT_BWD_S) acc = add4(acc, shfl_xor4(acc, off));
+    }
+    if (it.slot >= 0) {  // hub chunk: partial record [acc (W) | per head: unused, dsum]
+        if (sub == 0 && active) {
+            float *rec = P.partial + (size_t)it.slot * (size_t)(P.W + 2 * nk);
+            if (MODE == AGG_GAT_BWD_S) st4(rec + c4, acc);
+            if (c4 % P.F == 0) rec[P.W + 2 * k + 1] = dsum;
+        }
+        return;
+    }
+    if (P.self_loop) {
+        if (MODE == AGG_GAT_BWD_D) {
+            dsum += dz_edge_d<F4T>(P, rd, rd.hself, lane, pos, F4, pow2);
+        } else {
+            edge_s<F4T>(P, rs, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), true, lane,
+                        pos, F4, pow2, acc, dsum);
+        }
+    }
+    if (sub == 0 && active) {
+        if (MODE == AGG_GAT_BWD_D) finish_d(P, rd, row, c4, dsum);
+        else finish_s(P, rs, row, c4, acc, dsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ hub rows
+template <int G, int MODE, int F4T>
+__global__ __launch_bounds__(kBlock) void bwd_merge_kernel(const AggLaunch L) {
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int lane = (int)threadIdx.x % kWave;
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + (int)threadIdx.x / kWave;
+    if (item >= P.n_hub) return;
+    const int row = P.hub_rows[item];
+    const int first = P.hub_first[item], count = P.hub_count[item];
+    const int sub = lane / G, sl = lane % G;
+    const bool active = sl * 4 < P.W;
+    const int c4 = active ? sl * 4 : 0;
+    const int F4 = P.F / 4, pos = sl % F4;
+    const bool pow2 = (F4 & (F4 - 1)) == 0;
+    const int k = c4 / P.F, nk = P.W / P.F;
+    const size_t rec_sz = (size_t)(P.W + 2 * nk);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dsum = 0.f;
+    for (int c = 0; c < count; ++c) {  // chunk order, every subgroup the same value
+        const float *rec = P.partial + (size_t)(first + c) * rec_sz;
+        if (MODE == AGG_GAT_BWD_S) acc = add4(acc, ld4(rec + c4));
+        dsum += rec[P.W + 2 * k + 1];
+    }
+    if (MODE == AGG_GAT_BWD_D) {
+        const RowD r = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
+        if (P.self_loop) dsum += dz_edge_d<F4T>(P, r, r.hself, lane, pos, F4, pow2);
+        if (sub == 0 && active) finish_d(P, r, row, c4, dsum);
+    } else {
+        const RowS r = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
+        if (P.self_loop)
+            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), true, lane,
+                        pos, F4, pow2, acc, dsum);
+        if (sub == 0 && active) finish_s(P, r, row, c4, acc, dsum);
+    }
+}
+
+template <int G, int MODE, int F4T>
+int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
+    const char *nm = MODE == AGG_GAT_BWD_D ? "gat_bwd_dst" : "gat_bwd_src";
+    AggLaunch L;
+    for (int pass = 0; pass < 3; ++pass) {
+        L.n_groups = 0;
+        int blocks = 0;
+        for (int i = 0; i < n_sel; ++i) {
+            const AggGroup &g = base.g[sel[i]];
+            const int n = pass == 0 ? g.n_short : pass == 1 ? g.n_long : g.n_hub;
+            if (n <= 0) continue;
+            L.blk_start[L.n_groups] = blocks;
+            L.g[L.n_groups++] = g;
+            blocks += pass == 0 ? (n + (kBlock / G) - 1) / (kBlock / G) : pass == 1 ? ((n + 3) / 4 + 7) / 8 * 8 : (n + 3) / 4;
+        }
+        L.blk_start[L.n_groups] = blocks;
+        if (blocks == 0) continue;
+        ProfScope ps(nm, stream, 0.0);
+        if (pass == 0) hipLaunchKernelGGL((bwd_short_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        else if (pass == 1) hipLaunchKernelGGL((bwd_long_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        else hipLaunchKernelGGL((bwd_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        PEA_HIP(hipGetLastError());
+    }
+    return PEA_OK;
+}
+
+template <int G, int MODE>
+int launch_bwd_cls(const AggLaunch &base, int cls, const int *sel, int n, hipStream_t stream) {
+    if (cls == G) return launch_bwd_g<G, MODE, G>(base, sel, n, stream);
+    if (cls == 4) return launch_bwd_g<G, MODE, (G >= 4 ? 4 : 0)>(base, sel, n, stream);
+    return launch_bwd_g<G, MODE, 0>(base, sel, n, stream);
+}
+
+template <int MODE>
+int launch_bwd_mode(const AggLaunch &base, hipStream_t stream) {
+    const int classes[3] = {0, 4, -1};
+    for (int G = 4; G <= 64; G <<= 1)
+        for (int ci = 0; ci < 3; ++ci) {
+            const int cls = classes[ci] < 0 ? G : classes[ci];
+            if (ci == 1 && G == 4) continue;
+            int sel[kMaxAggGroups], n = 0;
+            for (int i = 0; i < base.n_groups; ++i) {
+                const int f4 = base.g[i].F / 4;
+                const int c = f4 == G ? G : f4 == 4 ? 4 : 0;
+                if (lanes_for(base.g[i].W) == G && c == cls) sel[n++] = i;
+            }
+            if (!n) continue;
+            switch (G) {
+                case 4: PEA_TRY((launch_bwd_cls<4, MODE>(base, cls, sel, n, stream))); break;
+                case 8: PEA_TRY((launch_bwd_cls<8, MODE>(base, cls, sel, n, stream))); break;
+                case 16: PEA_TRY((launch_bwd_cls<16, MODE>(base, cls, sel, n, stream))); break;
+                case 32: PEA_TRY((launch_bwd_cls<32, MODE>(base, cls, sel, n, stream))); break;
+                default: PEA_TRY((launch_bwd_cls<64, MODE>(base, cls, sel, n, stream))); break;
+            }
+        }
+    return PEA_OK;
+}
+
+// out[c] = sum_n A[n, c] * (S ? S[n, c / F] : 1) for c < W, rows in a fixed order (two stages, no atomics)
+__global__ __launch_bounds__(256) void colsum_stage1(int64_t N, int W, int F, const float *__restrict__ A, int lda,
+                                                     const float *__restrict__ S, int lds, float *__restrict__ part) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= W) return;
+    const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(N, r0 + rows_per);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += A[r * lda + c] * (S ? S[r * lds + c / F] : 1.f);
+    part[(size_t)blockIdx.x * W + c] = s;
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(int nparts, int W, const float *__restrict__ part, float scale,
+                                                     float *__restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= W) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * W + c];
+    out[c] = s * scale;
+}
+
+// in place: G[n, c] = O[n, c] > 0 ? G[n, c] : 0   (relu between steps, reference models/base.py:138)
+__global__ __launch_bounds__(256) void relu_mask_kernel(int64_t N, int W4, float *__restrict__ G, int ldg,
+                                                        const float *__restrict__ O, int ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * W4) return;
+    const int64_t r = idx / W4;
+    const int c = (int)(idx % W4) * 4;
+    float4 g = ld4(G + r * ldg + c);
+    const float4 o = ld4(O + r * ldo + c);
+    g.x = o.x > 0.f ? g.x : 0.f;
+    g.y = o.y > 0.f ? g.y : 0.f;
+    g.z = o.z > 0.f ? g.z : 0.f;
+    g.w = o.w > 0.f ? g.w : 0.f;
+    st4(G + r * ldg + c, g);
+}
+
+}  // namespace
+
+int launch_gat_backward(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream) {
+    PEA_REQUIRE(n_groups >= 0 && n_groups <= kMaxAggGroups, PEA_ERR_ARG, "gat backward: %d groups", n_groups);
+    AggLaunch base;
+    base.n_groups = n_groups;
+    for (int i = 0; i < n_groups; ++i) base.g[i] = groups[i];
+    return mode == AGG_GAT_BWD_D ? launch_bwd_mode<AGG_GAT_BWD_D>(base, stream) : launch_bwd_mode<AGG_GAT_BWD_S>(base, stream);
+}
+
+int launch_colsum(int64_t N, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
+                  float *out, hipStream_t stream) {
+    if (W <= 0) return PEA_OK;
+    ProfScope ps("colsum", stream, 0.0);
+    dim3 grid(kColsumParts, (unsigned)((W + 255) / 256));
+    hipLaunchKernelGGL(colsum_stage1, grid, dim3(256), 0, stream, N, W, F, A, lda, S, lds, part);
+    hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, kColsumParts, W, part, scale, out);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+int launch_relu_mask(int64_t N, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream) {
+    if (W <= 0 || N <= 0) return PEA_OK;
+    ProfScope ps("relu_mask", stream, 0.0);
+    const int64_t total = N * (W / 4);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, N, W / 4, G, ldg, O, ldo);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+}  // namespace pea

@@ -73,6 +73,7 @@ struct Relation {
     int *rowptr = nullptr;  // device [N+1]
     int *col = nullptr;     // device [e_kept] source ids, destination-sorted, stable
     float *dinv_row = nullptr, *dinv_col = nullptr;  // device [N], GCN deg^-1/2 (lazy)
+    float *invdeg = nullptr;                         // device [N], 1 / max(in-degree, 1) (SAGE backward, lazy)
     // work lists (device), restricted to the rows this rank owns
     int *short_rows = nullptr;   // owned rows with <= kShortDeg kept edges; the first n_short0 of them have none
     int n_short = 0, n_short0 = 0;
@@ -101,6 +102,7 @@ struct pea_plan {
     int gather_row_bytes = 0;  // hint: bytes of one gathered source row (0 = never slice by source)
     std::vector<pea::Relation> rels;
     int max_slots = 0;  // max hub chunks over relations (sizes the partial workspace)
+    float *ones = nullptr;      // device [N] of 1.0f (SAGE backward)
     int *owned_rows = nullptr;  // device, sharded plans only
     int64_t n_owned = 0;
 };
@@ -111,7 +113,10 @@ int ensure_dinv(pea_plan *plan, int rel, bool from_col, hipStream_t stream);
 int ensure_dinv_slots(pea_plan *plan, int rel, bool from_col, hipStream_t stream);
 
 // ---------------------------------------------------------------- aggregation (agg.hip)
-enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2 };
+// AGG_GAT_BWD_D / _S: the two gather passes of the GAT backward (agg.hip): D walks a destination row's in-edges
+// (gathers T_j) and yields d a_dst; S walks a source row's out-edges over the REVERSED relation (gathers the output
+// gradient rows g_i) and yields dT_j and d a_src.
+enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2, AGG_GAT_BWD_D = 3, AGG_GAT_BWD_S = 4 };
 
 // One horizontal group: C channel-heads of width F that share a relation, columns contiguous.
 struct AggGroup {
@@ -139,11 +144,28 @@ struct AggGroup {
     // bookkeeping for the live roofline measurement (messages reduced by the short / long launches; how many
     // reference conv calls share this group's index read)
     double msgs_short, msgs_long, idx_share;
+    // training: per (row, head) softmax statistics (m in the log2 domain, S) written by the GAT forward
+    float *stats;        // [N, ld_stats], already offset to this group's first head (2 floats per head)
+    int ld_stats;
+    // backward passes (see AggMode): row-local inputs indexed by node id, all offset to the group's first column/head
+    const float *g_self;   // D: output-gradient row of the destination (masked by relu), stride ld_g
+    const float *o_self;   // D: conv output row (post-relu O_s or X), stride ld_g
+    const float *side;     // S: gathered [a_dst, m, 1/(S+eps), c] per head, stride ld_side (indexed like `col`)
+    float *side_out;       // D: writes the same record for its row
+    float *ksum;           // D: d a_dst out / S: d a_src out, one float per head, stride ld_k
+    const float *da_dst;   // S: d a_dst of the row (from the D pass), stride ld_k
+    int ld_g, ld_side, ld_k;
 };
 
 constexpr int kMaxAggGroups = 16;
 int launch_aggregate(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream);
 size_t partial_record_floats(int W, int F);
+// backward helpers (agg_bwd.hip)
+constexpr int kColsumParts = 512;
+int launch_gat_backward(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream);
+int launch_colsum(int64_t N, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
+                  float *out, hipStream_t stream);
+int launch_relu_mask(int64_t N, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream);
 
 // ---------------------------------------------------------------- dense transform (gemm.hip)
 struct GemmSegment {   // output columns [c0, c1) of the job go to dst[row*ld + (c - c0)]
@@ -200,6 +222,10 @@ int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const C
 
 int model_forward(pea_model *m, int stage, const float *const *params, const float *x, int64_t ldx, const float *att,
                   int masked, float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x,
-                  int relu_last, hipStream_t stream);
+                  int relu_last, hipStream_t stream, bool training);
+
+}  // namespace pea
+float *aligned_ws(void *workspace);
+namespace pea {
 
 }  // namespace pea

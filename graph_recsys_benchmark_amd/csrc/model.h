@@ -1,0 +1,70 @@
+// Schedule data structures of one PEA model (built by model.hip, also read by the backward in model_bwd.hip).
+#pragma once
+#include "common.h"
+
+namespace pea {
+
+struct Unit {  // one channel at one level
+    int p = 0, s = 0, rel = 0;
+    int in_w = 0, heads = 1, F = 0, HF = 0;
+    bool last = false;
+    int in_col = 0;    // column of the input block (level 0: 0 in x; else in O_{s-1})
+    int t_col = 0;     // column in T_s (GAT/GCN) or of its mean block in M_s (SAGE)
+    int a_k = 0;       // first attention index in A_s
+    int o_col = 0;     // column in O_s (non-last) or X (last)
+    size_t b_off = 0;  // packed weight block (floats from the pack base)
+    int ldb = 0;
+    size_t bias_off = 0;
+};
+
+struct GroupPlan {  // one aggregation group of a level
+    int rel = 0;
+    int col = 0, W = 0, F = 0;  // columns [col, col+W) of the gather source
+    int a_k = 0;                // first attention index
+    bool last = false;
+    int out_col = 0;            // column in O_s / X (GAT/GCN) or M_s (SAGE)
+    size_t bias_off = 0;        // packed bias (floats from the pack base), GAT/GCN
+    size_t partial_off = 0;     // floats from the partial base
+    int n_convs = 1;            // reference conv calls this group serves (index reads it saves)
+    size_t xch_off = 0;         // sharded, level >= 1: exchange buffer [world*M rows, xch_ld] (floats from the workspace base)
+    int xch_ld = 0;
+};
+
+struct Level {
+    std::vector<Unit> units;  // in buffer (column) order
+    std::vector<GroupPlan> groups;
+    int n_cols = 0, n_heads = 0;             // sum HF, sum heads (GAT/GCN)
+    int ld_t = 0, ld_a = 0, ld_o = 0;        // strides of T_s (or M_s), A_s, O_s
+    size_t off_t = 0, off_a = 0, off_o = 0;  // float offsets in the workspace
+    bool shared_input = false;               // level 0 of GAT/GCN: one concatenated GEMM job
+    size_t b_off = 0, bias_off = 0;          // concatenated weight block / per-level bias block
+    size_t att_src_off = 0, att_dst_off = 0; // per-level att_j / att_i rows in column order (GAT)
+    int ldb = 0, n_out = 0;
+    // training / backward (allocated when the model was created with enable_backward)
+    int ld_stats = 0, ld_k = 0, ld_side = 0;             // strides of stats [N,2*heads], d a_* [N,heads], side [N,4*heads]
+    size_t off_stats = 0, off_dt = 0, off_do = 0, off_side = 0, off_dad = 0, off_das = 0;
+    size_t gatt_src_off = 0, gatt_dst_off = 0, gbias_off = 0;  // gradient rows (floats from the grad-pack base), column order
+};
+
+}  // namespace pea
+
+struct pea_model {
+    const pea_plan *plan = nullptr;
+    pea_model_desc d{};
+    std::vector<int> steps, relation_of;  // copies of the host arrays
+    std::vector<int> chan_first;          // index of (p,0) in relation_of
+    std::vector<pea::Level> levels;
+    int n_slots_per_layer = 0;
+    int ld_x = 0;
+    pea::ChanCols x_col{};                // column of channel p in X
+    size_t pack_floats = 0;               // workspace layout (floats): [pack | levels | X | partial]
+    size_t off_x = 0, off_partial = 0, partial_floats = 0;
+    size_t total_floats = 0;
+    int64_t messages = 0;
+    double alg_bytes = 0.0;
+    bool single_conv = false;             // pea_*_conv: any output width, X goes to the caller's buffer
+    bool backward = false;                // training buffers allocated
+    std::vector<int> reverse_of;          // relation -> index of the reversed relation in the plan (-1: absent)
+    size_t off_dx = 0, off_gpack = 0, gpack_floats = 0, off_colsum = 0;
+};
+

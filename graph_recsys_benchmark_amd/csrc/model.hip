@@ -18,66 +18,7 @@
 #include <algorithm>
 #include <cstring>
 
-#include "common.h"
-
-namespace pea {
-
-struct Unit {  // one channel at one level
-    int p = 0, s = 0, rel = 0;
-    int in_w = 0, heads = 1, F = 0, HF = 0;
-    bool last = false;
-    int in_col = 0;    // column of the input block (level 0: 0 in x; else in O_{s-1})
-    int t_col = 0;     // column in T_s (GAT/GCN) or of its mean block in M_s (SAGE)
-    int a_k = 0;       // first attention index in A_s
-    int o_col = 0;     // column in O_s (non-last) or X (last)
-    size_t b_off = 0;  // packed weight block (floats from the pack base)
-    int ldb = 0;
-    size_t bias_off = 0;
-};
-
-struct GroupPlan {  // one aggregation group of a level
-    int rel = 0;
-    int col = 0, W = 0, F = 0;  // columns [col, col+W) of the gather source
-    int a_k = 0;                // first attention index
-    bool last = false;
-    int out_col = 0;            // column in O_s / X (GAT/GCN) or M_s (SAGE)
-    size_t bias_off = 0;        // packed bias (floats from the pack base), GAT/GCN
-    size_t partial_off = 0;     // floats from the partial base
-    int n_convs = 1;            // reference conv calls this group serves (index reads it saves)
-    size_t xch_off = 0;         // sharded, level >= 1: exchange buffer [world*M rows, xch_ld] (floats from the workspace base)
-    int xch_ld = 0;
-};
-
-struct Level {
-    std::vector<Unit> units;  // in buffer (column) order
-    std::vector<GroupPlan> groups;
-    int n_cols = 0, n_heads = 0;             // sum HF, sum heads (GAT/GCN)
-    int ld_t = 0, ld_a = 0, ld_o = 0;        // strides of T_s (or M_s), A_s, O_s
-    size_t off_t = 0, off_a = 0, off_o = 0;  // float offsets in the workspace
-    bool shared_input = false;               // level 0 of GAT/GCN: one concatenated GEMM job
-    size_t b_off = 0, bias_off = 0;          // concatenated weight block / per-level bias block
-    size_t att_src_off = 0, att_dst_off = 0; // per-level att_j / att_i rows in column order (GAT)
-    int ldb = 0, n_out = 0;
-};
-
-}  // namespace pea
-
-struct pea_model {
-    const pea_plan *plan = nullptr;
-    pea_model_desc d{};
-    std::vector<int> steps, relation_of;  // copies of the host arrays
-    std::vector<int> chan_first;          // index of (p,0) in relation_of
-    std::vector<pea::Level> levels;
-    int n_slots_per_layer = 0;
-    int ld_x = 0;
-    pea::ChanCols x_col{};                // column of channel p in X
-    size_t pack_floats = 0;               // workspace layout (floats): [pack | levels | X | partial]
-    size_t off_x = 0, off_partial = 0, partial_floats = 0;
-    size_t total_floats = 0;
-    int64_t messages = 0;
-    double alg_bytes = 0.0;
-    bool single_conv = false;             // pea_*_conv: any output width, X goes to the caller's buffer
-};
+#include "model.h"
 
 namespace pea {
 namespace {
@@ -96,6 +37,14 @@ int width_out(const pea_model_desc &d, int S, int s, int *heads_out) {
     if (S > 1 && last) heads = 1;
     *heads_out = heads;
     return last ? d.repr_dim : d.hidden_size;
+}
+
+// hub chunks a group may need: its relation's, or (training) the reversed relation's the backward walks
+int slots_of(const pea_model *m, int rel) {
+    int n = m->plan->rels[(size_t)rel].n_slots;
+    if (m->backward && rel < (int)m->reverse_of.size() && m->reverse_of[(size_t)rel] >= 0)
+        n = std::max(n, m->plan->rels[(size_t)m->reverse_of[(size_t)rel]].n_slots);
+    return n;
 }
 
 int rel_at(const pea_model *m, int p, int s) { return m->relation_of[(size_t)(m->chan_first[(size_t)p] + s)]; }
@@ -246,7 +195,7 @@ int build_schedule(pea_model *m) {
                     g.F = g.W;
                     g.out_col = mcol + (c - c_beg);
                     g.partial_off = partial;
-                    partial += (size_t)plan->rels[(size_t)g.rel].n_slots * partial_record_floats(g.W, g.F);
+                    partial += (size_t)slots_of(m, g.rel) * partial_record_floats(g.W, g.F);
                     L.groups.push_back(g);
                 }
                 mcol += c_end - c_beg;
@@ -274,7 +223,7 @@ int build_schedule(pea_model *m) {
                     for (size_t k = i; k < j; ++k)
                         if (L.units[k].t_col < c + g.W && L.units[k].t_col + L.units[k].HF > c) ++g.n_convs;
                     g.partial_off = partial;
-                    partial += (size_t)plan->rels[(size_t)g.rel].n_slots * partial_record_floats(g.W, g.F);
+                    partial += (size_t)slots_of(m, g.rel) * partial_record_floats(g.W, g.F);
                     L.groups.push_back(g);
                 }
                 i = j;
@@ -327,6 +276,24 @@ int build_schedule(pea_model *m) {
         for (GroupPlan &g : L.groups)
             if (g.xch_ld) g.xch_off += off;
     off += xch;
+    if (m->backward) {  // training: softmax statistics, gradient buffers, gradient pack (same layout as the weight pack)
+        int max_w = 4;
+        for (Level &L : m->levels) {
+            L.ld_stats = pad4(2 * std::max(L.n_heads, 1));
+            L.ld_k = pad4(std::max(L.n_heads, 1));
+            L.ld_side = pad4(4 * std::max(L.n_heads, 1));
+            L.off_stats = off; off = pad_off(off + (size_t)N * (size_t)L.ld_stats);
+            L.off_dt = off;    off = pad_off(off + (size_t)N * (size_t)L.ld_t);
+            L.off_do = off;    off = pad_off(off + (size_t)N * (size_t)std::max(L.ld_o, 4));
+            L.off_side = off;  off = pad_off(off + (size_t)N * (size_t)std::max(L.ld_side, sage ? L.ld_t : 4));
+            L.off_dad = off;   off = pad_off(off + (size_t)N * (size_t)L.ld_k);
+            L.off_das = off;   off = pad_off(off + (size_t)N * (size_t)L.ld_k);
+            max_w = std::max(max_w, std::max(L.ld_t, L.ld_o));
+        }
+        m->off_dx = off;      off = pad_off(off + (size_t)N * (size_t)m->ld_x);
+        m->off_gpack = off;   m->gpack_floats = m->pack_floats; off = pad_off(off + m->gpack_floats);
+        m->off_colsum = off;  off = pad_off(off + (size_t)kColsumParts * (size_t)std::max(max_w, m->ld_x));
+    }
     m->total_floats = off;
     return PEA_OK;
 }
@@ -350,8 +317,16 @@ int init_model(pea_model *m, const pea_plan *plan, const pea_model_desc *desc) {
         total += m->steps[(size_t)p];
     }
     m->relation_of.assign(desc->relation_of, desc->relation_of + total);
+    m->backward = desc->enable_backward != 0;
+    m->reverse_of.clear();
+    if (m->backward) {
+        PEA_REQUIRE(desc->reverse_of != nullptr, PEA_ERR_ARG, "model: enable_backward needs reverse_of (relation -> reversed relation)");
+        PEA_REQUIRE(plan->shard_world == 1, PEA_ERR_ARG, "model: the backward pass is single-GPU for now");
+        m->reverse_of.assign(desc->reverse_of, desc->reverse_of + plan->rels.size());
+    }
     m->d.steps = nullptr;
     m->d.relation_of = nullptr;
+    m->d.reverse_of = nullptr;
     m->n_slots_per_layer = desc->kind == PEA_KIND_GAT ? 4 : desc->kind == PEA_KIND_GCN ? 2 : 3;
     return build_schedule(m);
 }
@@ -363,7 +338,7 @@ int init_model(pea_model *m, const pea_plan *plan, const pea_model_desc *desc) {
 // entry points); relu_last applies relu to last layers too.
 int model_forward(pea_model *m, int stage, const float *const *params, const float *x, int64_t ldx, const float *att,
                   int masked, float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x, int relu_last,
-                  hipStream_t stream) {
+                  hipStream_t stream, bool training) {
     const pea_model_desc &d = m->d;
     pea_plan *plan = const_cast<pea_plan *>(m->plan);
     const int64_t N = plan->N;
@@ -463,7 +438,11 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             a.n_short = R.n_short;
             // rows without incoming edges of a layer that feeds another layer are not aggregated at all: the next
             // transform reads T_s for them (GemmJob::a1_mask)
-            const bool skip0 = mode != AGG_MEAN && !g.last && (plan->flags & PEA_PLAN_SELF_LOOPS);
+            const bool skip0 = mode != AGG_MEAN && !g.last && (plan->flags & PEA_PLAN_SELF_LOOPS) && !training;
+            if (training && mode == AGG_GAT) {  // keep (max, denominator) per (row, head) for the backward
+                a.stats = wsf + L.off_stats + 2 * g.a_k;
+                a.ld_stats = L.ld_stats;
+            }
             if (skip0) {
                 a.short_rows = R.short_rows + R.n_short0;
                 a.n_short = R.n_short - R.n_short0;
@@ -617,7 +596,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             J.seg[0].c1 = u.HF;
             J.seg[0].dst = T + u.t_col;
             J.seg[0].ld = L.ld_t;
-            if (plan->flags & PEA_PLAN_SELF_LOOPS) {  // edge-less rows of the previous layer: read T_{s-1} (see run_groups)
+            if ((plan->flags & PEA_PLAN_SELF_LOOPS) && !training) {  // edge-less rows of the previous layer: read T_{s-1} (see run_groups)
                 for (const Unit &up : Lp.units) {
                     if (up.p != u.p) continue;
                     Relation &Rp = plan->rels[(size_t)up.rel];
@@ -695,7 +674,7 @@ extern "C" int pea_model_stats(const pea_model *model, int64_t *messages, double
     return PEA_OK;
 }
 
-static float *aligned_ws(void *workspace) {
+float *aligned_ws(void *workspace) {
     return reinterpret_cast<float *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
 }
 
@@ -709,7 +688,19 @@ extern "C" int pea_model_forward(pea_model *model, const float *const *params_ho
     PEA_REQUIRE(out_repr || out_stack, PEA_ERR_ARG, "forward: no output requested");
     PEA_REQUIRE(model->d.fuse_mode == PEA_FUSE_MEAN || att || !out_repr, PEA_ERR_ARG, "forward: att is required for 'att' fusion");
     return model_forward(model, -1, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
-                         out_stack, nullptr, 0, 0, (hipStream_t)stream);
+                         out_stack, nullptr, 0, 0, (hipStream_t)stream, false);
+}
+
+extern "C" int pea_model_forward_train(pea_model *model, const float *const *params_host, const float *x, const float *att,
+                                       int masked_channel, void *workspace, size_t workspace_bytes, float *out_repr,
+                                       float *out_stack, void *stream) {
+    PEA_REQUIRE(model && params_host && x && workspace, PEA_ERR_ARG, "forward_train: null argument");
+    PEA_REQUIRE(model->backward, PEA_ERR_ARG, "forward_train: the model was created without enable_backward");
+    PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(model), PEA_ERR_NOMEM, "forward_train: workspace too small");
+    PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward_train: masked channel");
+    PEA_REQUIRE(out_repr || out_stack, PEA_ERR_ARG, "forward_train: no output requested");
+    return model_forward(model, -1, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
+                         out_stack, nullptr, 0, 0, (hipStream_t)stream, true);
 }
 
 extern "C" int pea_model_num_stages(const pea_model *model) { return model ? (int)model->levels.size() : 0; }
@@ -723,7 +714,7 @@ extern "C" int pea_model_forward_stage(pea_model *model, int stage, const float 
     PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(model), PEA_ERR_NOMEM, "forward_stage: workspace too small");
     PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward_stage: masked channel %d", masked_channel);
     return model_forward(model, stage, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
-                         out_stack, nullptr, 0, 0, (hipStream_t)stream);
+                         out_stack, nullptr, 0, 0, (hipStream_t)stream, false);
 }
 
 extern "C" int pea_model_num_exchanges(const pea_model *model, int level) {
@@ -778,7 +769,7 @@ static int single_conv(int kind, const pea_plan *plan, int relation, int in_chan
                 "conv: row strides (%lld, %lld) must be multiples of 4 covering the row", (long long)ldx, (long long)ldo);
     PEA_REQUIRE(workspace_bytes >= m.total_floats * sizeof(float) + 256, PEA_ERR_NOMEM, "conv: workspace too small");
     return model_forward(&m, -1, params, x, ldx, nullptr, -1, aligned_ws(workspace), nullptr, nullptr, out, ldo, relu,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, false);
 }
 
 extern "C" int pea_gat_conv(const pea_plan *plan, int relation, int in_channels, int heads, int out_channels, const float *x,

@@ -1,0 +1,213 @@
+// Backward of one level of the PEA schedule (training; reference solvers.py:215 loss.backward()).
+// The sparse half -- gradient gathers over the reversed relations, relu masks, bias / attention-vector gradient
+// reductions -- runs here; the dense half (dW = In^T dT, dIn = dT W: plain GEMMs) is done by the host mirror with
+// rocBLAS through torch.mm on views of the same workspace (graph_recsys_benchmark_amd/autograd.py).
+//
+// Workspace regions (model.h): dX [N, ld_x] gradient of the last-layer outputs (internal column order), per level
+// dO_s [N, ld_o] gradient of the relu(conv) outputs, dT_s [N, ld_t] gradient of the transformed features (SAGE: of the
+// neighbour means), side_s / dad_s / das_s GAT per-head records, gpack: bias / att gradients at the SAME offsets as
+// their values in the weight pack.
+#include "model.h"
+
+namespace pea {
+namespace {
+
+__global__ void fill_kernel(int64_t n, float v, float *p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void invdeg_kernel(int64_t N, const int *__restrict__ rowptr, float *__restrict__ out) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int d = rowptr[v + 1] - rowptr[v];
+    out[v] = 1.0f / (float)(d < 1 ? 1 : d);
+}
+
+int ensure_sage_arrays(pea_plan *plan, int rel, hipStream_t stream) {
+    const int64_t N = plan->N;
+    if (!plan->ones) {
+        PEA_HIP(hipMalloc((void **)&plan->ones, (size_t)N * sizeof(float)));
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, 1.0f, plan->ones);
+    }
+    Relation &R = plan->rels[(size_t)rel];
+    if (!R.invdeg) {
+        PEA_HIP(hipMalloc((void **)&R.invdeg, (size_t)N * sizeof(float)));
+        hipLaunchKernelGGL(invdeg_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, R.rowptr, R.invdeg);
+    }
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+void fill_lists(AggGroup &a, const Relation &R) {
+    a.rowptr = R.rowptr;
+    a.col = R.col;
+    a.short_rows = R.short_rows;
+    a.long_items = R.long_items;
+    a.hub_rows = R.hub_rows;
+    a.hub_first = R.hub_first;
+    a.hub_count = R.hub_count;
+    a.n_short = R.n_short;
+    a.n_long = R.n_long;
+    a.n_hub = R.n_hub;
+}
+
+}  // namespace
+}  // namespace pea
+
+using namespace pea;
+
+// phase 0: relu masks + bias gradients (all kinds); GAT/GCN: the aggregation backward -> dT_s (+ att gradients)
+// phase 1: SAGE only: reverse mean aggregation of dM_s (written by the host into the dT_s region) -> side_s region
+extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void *workspace, size_t workspace_bytes,
+                                        void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PEA_REQUIRE(m && workspace && m->backward, PEA_ERR_ARG, "backward: model without enable_backward");
+    PEA_REQUIRE(level >= 0 && level < (int)m->levels.size() && (phase == 0 || phase == 1), PEA_ERR_ARG, "backward: level %d phase %d", level, phase);
+    PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(m), PEA_ERR_NOMEM, "backward: workspace too small");
+    float *wsf = aligned_ws(workspace);
+    pea_plan *plan = const_cast<pea_plan *>(m->plan);
+    const pea_model_desc &d = m->d;
+    const int64_t N = plan->N;
+    Level &L = m->levels[(size_t)level];
+    float *pack = wsf, *gpack = wsf + m->off_gpack, *colsum_part = wsf + m->off_colsum;
+    float *T = wsf + L.off_t, *O = wsf + L.off_o, *X = wsf + m->off_x;
+    float *dT = wsf + L.off_dt, *dO = wsf + L.off_do, *dX = wsf + m->off_dx;
+    float *partial = wsf + m->off_partial;
+    const bool loops = plan->flags & PEA_PLAN_SELF_LOOPS;
+
+    if (d.kind == PEA_KIND_SAGE) {
+        if (phase == 0) {
+            for (const Unit &u : L.units) {
+                float *G = u.last ? dX + u.o_col : dO + u.o_col;
+                const float *Out = u.last ? X + u.o_col : O + u.o_col;
+                const int ldg = u.last ? m->ld_x : L.ld_o;
+                if (!u.last) PEA_TRY(launch_relu_mask(N, u.HF, G, ldg, Out, ldg, stream));
+                PEA_TRY(launch_colsum(N, u.HF, u.HF, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + u.bias_off, stream));
+            }
+            return PEA_OK;
+        }
+        std::vector<AggGroup> gs;
+        for (const GroupPlan &g : L.groups) {
+            const int rr = m->reverse_of[(size_t)g.rel];
+            PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", g.rel);
+            PEA_TRY(ensure_sage_arrays(plan, g.rel, stream));
+            AggGroup a{};
+            fill_lists(a, plan->rels[(size_t)rr]);
+            a.W = g.W;
+            a.F = g.W;
+            a.feat = dT + g.out_col;  // dM columns of this group
+            a.ld_feat = L.ld_t;
+            a.feat_self = a.feat;
+            a.ld_self = L.ld_t;
+            a.dinv = plan->rels[(size_t)g.rel].invdeg;  // 1 / max(deg_i, 1) of the gathered (forward destination) node
+            a.dinv_self = plan->ones;
+            a.out = wsf + L.off_side + g.out_col;       // gradient wrt the gathered input columns, M_s column layout
+            a.ld_out = L.ld_t;
+            a.partial = partial + g.partial_off;
+            gs.push_back(a);
+        }
+        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+            PEA_TRY(launch_aggregate(AGG_GCN, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        return PEA_OK;
+    }
+
+    PEA_REQUIRE(phase == 0, PEA_ERR_ARG, "backward: GAT/GCN levels have a single phase");
+    std::vector<AggGroup> gd, gsrc;
+    for (const GroupPlan &g : L.groups) {
+        const int rr = m->reverse_of[(size_t)g.rel];
+        PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", g.rel);
+        Relation &R = plan->rels[(size_t)g.rel], &Rr = plan->rels[(size_t)rr];
+        PEA_REQUIRE(Rr.n_slots * partial_record_floats(g.W, g.F) <= m->partial_floats, PEA_ERR_NOMEM,
+                    "backward: hub partial buffer too small for the reversed relation");
+        float *G = g.last ? dX + g.out_col : dO + g.out_col;
+        const float *Out = g.last ? X + g.out_col : O + g.out_col;
+        const int ldg = g.last ? m->ld_x : L.ld_o;
+        if (!g.last) PEA_TRY(launch_relu_mask(N, g.W, G, ldg, Out, ldg, stream));
+        PEA_TRY(launch_colsum(N, g.W, g.W, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + g.bias_off, stream));
+        AggGroup a{};
+        a.W = g.W;
+        a.F = g.F;
+        a.neg_slope = d.negative_slope;
+        a.self_loop = loops ? 1 : 0;
+        a.partial = partial;  // one group at a time below (the buffer is reused)
+        if (d.kind == PEA_KIND_GCN) {
+            const bool fc = d.gcn_deg_from_col != 0;
+            PEA_TRY(ensure_dinv(plan, g.rel, fc, stream));
+            fill_lists(a, Rr);
+            a.feat = G;
+            a.ld_feat = ldg;
+            a.feat_self = G;
+            a.ld_self = ldg;
+            a.dinv = fc ? R.dinv_col : R.dinv_row;
+            a.dinv_self = a.dinv;
+            a.out = dT + g.col;
+            a.ld_out = L.ld_t;
+            PEA_TRY(launch_aggregate(AGG_GCN, &a, 1, stream));
+            continue;
+        }
+        a.att_src = pack + L.att_src_off + g.col;
+        a.att_dst = pack + L.att_dst_off + g.col;
+        a.bias = pack + g.bias_off;
+        a.ld_side = L.ld_side;
+        a.ld_k = L.ld_k;
+        a.ld_g = ldg;
+        // D pass: destination rows of the forward relation, gathers T_j
+        AggGroup D = a;
+        fill_lists(D, R);
+        D.feat = T + g.col;
+        D.ld_feat = L.ld_t;
+        D.feat_self = D.feat;
+        D.ld_self = L.ld_t;
+        D.g_self = G;
+        D.o_self = Out;
+        D.stats = wsf + L.off_stats + 2 * g.a_k;
+        D.ld_stats = L.ld_stats;
+        D.side_out = wsf + L.off_side + 4 * g.a_k;
+        D.ksum = wsf + L.off_dad + g.a_k;
+        PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, &D, 1, stream));
+        // S pass: source rows = destination rows of the reversed relation, gathers g_i and the side records
+        AggGroup S = a;
+        fill_lists(S, Rr);
+        S.feat = G;
+        S.ld_feat = ldg;
+        S.feat_self = T + g.col;
+        S.ld_self = L.ld_t;
+        S.side = wsf + L.off_side + 4 * g.a_k;
+        S.da_dst = wsf + L.off_dad + g.a_k;
+        S.ksum = wsf + L.off_das + g.a_k;
+        S.out = dT + g.col;
+        S.ld_out = L.ld_t;
+        PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, &S, 1, stream));
+        // d att_j[c] = sum_n d a_src[n, head(c)] T[n, c],  d att_i likewise with d a_dst
+        PEA_TRY(launch_colsum(N, g.W, g.F, T + g.col, L.ld_t, wsf + L.off_das + g.a_k, L.ld_k, 1.0f, colsum_part,
+                              gpack + L.att_src_off + g.col, stream));
+        PEA_TRY(launch_colsum(N, g.W, g.F, T + g.col, L.ld_t, wsf + L.off_dad + g.a_k, L.ld_k, 1.0f, colsum_part,
+                              gpack + L.att_dst_off + g.col, stream));
+    }
+    return PEA_OK;
+}
+
+// Flat description of the schedule for the host mirror (all offsets in floats from the 256-byte aligned workspace base):
+//   [0] n_levels  [1] ld_x  [2] off_x  [3] off_dx  [4] off_gpack  [5] pack_floats  then per level
+//   ld_t ld_o off_t off_o off_dt off_do off_side bias_off att_src_off att_dst_off n_units, then per unit
+//   p s rel in_w heads F HF last in_col t_col o_col b_off ldb bias_off
+extern "C" int pea_model_describe(const pea_model *m, int64_t *out, int max_len, int *needed) {
+    PEA_REQUIRE(m && needed, PEA_ERR_ARG, "describe: null");
+    std::vector<int64_t> v = {(int64_t)m->levels.size(), m->ld_x, (int64_t)m->off_x, (int64_t)m->off_dx,
+                              (int64_t)m->off_gpack, (int64_t)m->pack_floats};
+    for (const Level &L : m->levels) {
+        const int64_t head[] = {L.ld_t, L.ld_o, (int64_t)L.off_t, (int64_t)L.off_o, (int64_t)L.off_dt, (int64_t)L.off_do,
+                                (int64_t)L.off_side, (int64_t)L.bias_off, (int64_t)L.att_src_off, (int64_t)L.att_dst_off,
+                                (int64_t)L.units.size()};
+        v.insert(v.end(), head, head + 11);
+        for (const Unit &u : L.units) {
+            const int64_t un[] = {u.p, u.s, u.rel, u.in_w, u.heads, u.F, u.HF, u.last ? 1 : 0, u.in_col, u.t_col, u.o_col,
+                                  (int64_t)u.b_off, u.ldb, (int64_t)u.bias_off};
+            v.insert(v.end(), un, un + 14);
+        }
+    }
+    *needed = (int)v.size();
+    if (out && max_len >= (int)v.size()) std::copy(v.begin(), v.end(), out);
+    return PEA_OK;
+}

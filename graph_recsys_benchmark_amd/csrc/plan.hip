@@ -373,7 +373,7 @@ __global__ void scatter_to_slots(int64_t N, const int *__restrict__ slot_of_node
 void free_relation(Relation &R) {
     (void)hipFree(R.col_slot); (void)hipFree(R.dinv_row_slot); (void)hipFree(R.dinv_col_slot);
     (void)hipFree(R.slot_of_node); (void)hipFree(R.need_rows);
-    (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col);
+    (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col); (void)hipFree(R.invdeg);
     (void)hipFree(R.short_rows); (void)hipFree(R.long_items); (void)hipFree(R.deg0);
     (void)hipFree(R.hub_rows); (void)hipFree(R.hub_first); (void)hipFree(R.hub_count);
 }
@@ -507,6 +507,7 @@ extern "C" int pea_plan_destroy(pea_plan *plan) {
     if (!plan) return PEA_OK;
     for (auto &R : plan->rels) pea::free_relation(R);
     (void)hipFree(plan->owned_rows);
+    (void)hipFree(plan->ones);
     delete plan;
     return PEA_OK;
 }

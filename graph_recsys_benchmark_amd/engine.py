@@ -39,7 +39,7 @@ class GraphPlan:
     """
 
     def __init__(self, num_nodes, meta_path_edge_index_list, self_loops, shard_rank=0, shard_world=1,
-                 shard_tile=256, gather_row_bytes=256):
+                 shard_tile=256, gather_row_bytes=256, with_reverse=False):
         lib = _lib.require_device()
         self.num_nodes = int(num_nodes)
         self.self_loops = bool(self_loops)
@@ -66,6 +66,26 @@ class GraphPlan:
                     keys.setdefault(fp, []).append(found)
                 row.append(found)
             self.relation_of.append(row)
+        # training: the backward gathers run over the REVERSED relations; add the ones the model does not use itself
+        self.reverse_of = None
+        if with_reverse:
+            self.reverse_of = []
+            for r in range(len(uniq)):
+                flipped = torch.flip(uniq[r], dims=[0]).contiguous()
+                fp = _fingerprint(flipped)
+                found = None
+                for cand in keys.get(fp, []):
+                    if torch.equal(uniq[cand], flipped):
+                        found = cand
+                        break
+                if found is None:
+                    found = len(uniq)
+                    uniq.append(flipped)
+                    keys.setdefault(fp, []).append(found)
+                self.reverse_of.append(found)
+            # reversed relations appended above get their own entry too (reverse of a reverse is the original)
+            for r in range(len(self.reverse_of), len(uniq)):
+                self.reverse_of.append(next(i for i, rr in enumerate(self.reverse_of) if rr == r))
         self.num_relations = len(uniq)
         ptrs = (C.c_void_p * len(uniq))(*[t.data_ptr() for t in uniq])
         nedge = (C.c_int64 * len(uniq))(*[t.shape[1] for t in uniq])
@@ -114,7 +134,7 @@ class PEAEngine:
     """One scheduled PEA forward: P channels x S conv layers of one kind, then fusion."""
 
     def __init__(self, plan, kind, steps, emb_dim, hidden_size, repr_dim, heads=1, channel_aggr='att',
-                 gcn_deg_from='row', negative_slope=0.2):
+                 gcn_deg_from='row', negative_slope=0.2, enable_backward=False):
         if channel_aggr not in ('att', 'mean'):
             # 'concat' cannot work in the reference either (models/base.py:175 sizes fc1 for 'cat')
             raise NotImplementedError('Other aggr methods not implemeted!')
@@ -133,9 +153,16 @@ class PEAEngine:
         flat = [r for row in plan.relation_of for r in row]
         self._steps_c = (C.c_int * self.P)(*self.steps)
         self._rel_c = (C.c_int * len(flat))(*flat)
+        self.enable_backward = bool(enable_backward)
+        self._rev_c = None
+        if self.enable_backward:
+            if plan.reverse_of is None:
+                raise ValueError('training needs a GraphPlan built with with_reverse=True')
+            self._rev_c = (C.c_int * len(plan.reverse_of))(*plan.reverse_of)
         desc = _lib.ModelDesc(KINDS[kind], self.P, self._steps_c, self._rel_c, int(emb_dim), int(hidden_size),
                               int(repr_dim), int(heads), _lib.FUSE_ATT if channel_aggr == 'att' else _lib.FUSE_MEAN,
-                              1 if gcn_deg_from == 'col' else 0, float(negative_slope))
+                              1 if gcn_deg_from == 'col' else 0, float(negative_slope), 1 if self.enable_backward else 0,
+                              self._rev_c)
         handle = C.c_void_p()
         _lib.check(lib.pea_model_create(plan._h, C.byref(desc), C.byref(handle)))
         self._h = handle
@@ -165,9 +192,9 @@ class PEAEngine:
                     row.append((d, src, dst, plan.source_layouts[d.relation]))
                 self._exchanges.append(row)
 
-    def forward(self, layer_params, x, att=None, masked=None, want_stack=False):
+    def forward(self, layer_params, x, att=None, masked=None, want_stack=False, train=False):
         """layer_params: list (channel-major, then step) of tuples of tensors in PARAM_SLOTS order
-        (a missing bias may be None)."""
+        (a missing bias may be None).  train=True keeps what backward() needs (single GPU)."""
         lib = _lib.load()
         n = self.plan.num_nodes
         if x.shape != (n, self.emb_dim) or x.dtype != torch.float32 or not x.is_cuda:
@@ -201,9 +228,12 @@ class PEAEngine:
         stack = torch.empty((n, self.P, self.repr_dim), dtype=torch.float32, device=x.device) if want_stack else None
         m = -1 if masked is None else int(masked)
         if not self.sharded:
-            _lib.check(lib.pea_model_forward(self._h, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m, _lib.ptr(self._ws),
-                                             self.workspace_bytes, _lib.ptr(out), _lib.ptr(stack), _lib.current_stream()))
+            fn = lib.pea_model_forward_train if train else lib.pea_model_forward
+            _lib.check(fn(self._h, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m, _lib.ptr(self._ws),
+                          self.workspace_bytes, _lib.ptr(out), _lib.ptr(stack), _lib.current_stream()))
             return (out, stack) if want_stack else out
+        if train:
+            raise NotImplementedError('the backward pass is single-GPU for now')
         # Sharded forward: stage k computes this rank's rows of level k (and the transform feeding level k+1); the
         # gather sources of level k+1 are then all-gathered from their owners; after the last stage the fused rows
         # (not the per-metapath stack) are all-gathered: the fusion is row-local under row ownership.

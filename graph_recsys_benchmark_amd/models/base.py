@@ -7,12 +7,14 @@ Mirrors (names, kwargs, attributes, error behaviour) graph_recsys_benchmark/mode
 Differences, all on purpose:
   * forward() hands ALL channels and steps to one schedule (engine.PEAEngine) instead of looping in Python;
   * graph tensors must be on the GPU; there is no CPU fallback (parity checks use oracle/ from the tests);
-  * forward-only so far: loss() in training mode with autograd enabled raises (backward = SURVEY 8f rank 1).
+  * with autograd enabled (training), the conv stack runs through autograd.PEAStackFunction (HIP forward AND
+    backward); the cheap fusion + scorer on top of it are plain differentiable torch ops.
 """
 import torch
 from torch.nn import Parameter
 
 from .. import engine as _engine
+from ..autograd import PEAStackFunction
 from ..nn.inits import glorot
 
 
@@ -38,17 +40,18 @@ class GraphRecsysModel(torch.nn.Module):
         """-sum(log(sigmoid(pos - neg))) over rows (u, i+, i-[, entity columns]); in training mode the full-graph
         forward is recomputed first, exactly like the reference (models/base.py:44-45)."""
         if self.training:
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError(
-                    'the HIP path is forward-only so far (backward is SURVEY.md section 8f rank 1); '
-                    'run training-mode loss() under torch.no_grad()')
             self.cached_repr = self.forward()
-        cf_loss = _engine.bpr_score(self.cached_repr, pos_neg_pair_t, self.fc1.weight, self.fc1.bias,
-                                    self.fc2.weight, self.fc2.bias)
+        if self.cached_repr.requires_grad:      # differentiable path (same formula as the reference, models/base.py:46-48)
+            pos_pred = self.predict(pos_neg_pair_t[:, 0], pos_neg_pair_t[:, 1])
+            neg_pred = self.predict(pos_neg_pair_t[:, 0], pos_neg_pair_t[:, 2])
+            cf_loss = -(pos_pred - neg_pred).sigmoid().log().sum()
+        else:
+            cf_loss = _engine.bpr_score(self.cached_repr, pos_neg_pair_t, self.fc1.weight, self.fc1.bias,
+                                        self.fc2.weight, self.fc2.bias)
         if self.entity_aware and self.training:
             # entity-aware regulariser (models/base.py:50-76): squared L2 distances between raw x rows
             t = pos_neg_pair_t
-            x = self.x.detach()
+            x = self.x if self.cached_repr.requires_grad else self.x.detach()
 
             def sqdist(a, b):
                 d = x[t[:, a]] - x[t[:, b]]
@@ -120,13 +123,15 @@ class PEABaseRecsysModel(GraphRecsysModel):
         self.fc2 = torch.nn.Linear(kwargs['repr_dim'], 1)
         self._dims = (kwargs['emb_dim'], kwargs['hidden_size'], kwargs['repr_dim'], kwargs.get('num_heads', 1))
         self._engine = None
+        self._train_engine = None
+        self._plan = None
         self._shard = (0, 1, 256)
 
     def shard(self, rank, world, tile=256):
         """Multi-GPU: this process computes the destination rows it owns (row i -> rank (i // tile) % world);
         torch.distributed must be initialised (backend 'nccl' = RCCL on the GPUs)."""
         self._shard = (int(rank), int(world), int(tile))
-        self._engine = None
+        self._engine = self._train_engine = self._plan = None
         return self
 
     def reset_parameters(self):
@@ -140,19 +145,26 @@ class PEABaseRecsysModel(GraphRecsysModel):
             glorot(self.att)
 
     # ------------------------------------------------------------------ HIP schedule
-    def _get_engine(self):
-        if self._engine is None:
-            if self.channel_aggr not in ('att', 'mean'):
-                raise NotImplementedError('Other aggr methods not implemeted!')
-            emb, hidden, repr_dim, heads = self._dims
-            plan = _engine.GraphPlan(self.x.shape[0], self.meta_path_edge_index_list,
-                                     self_loops=self.kind in ('gat', 'gcn'), shard_rank=self._shard[0],
-                                     shard_world=self._shard[1], shard_tile=self._shard[2],
-                                     gather_row_bytes=4 * hidden * (heads if self.kind == 'gat' else 1))
-            self._engine = _engine.PEAEngine(plan, self.kind, self.meta_path_steps, emb, hidden, repr_dim,
-                                             heads=heads if self.kind == 'gat' else 1,
-                                             channel_aggr=self.channel_aggr, gcn_deg_from=self.gcn_deg_from)
-        return self._engine
+    def _get_engine(self, train=False):
+        if self.channel_aggr not in ('att', 'mean'):
+            raise NotImplementedError('Other aggr methods not implemeted!')
+        emb, hidden, repr_dim, heads = self._dims
+        single = self._shard[1] == 1
+        if self._plan is None:
+            self._plan = _engine.GraphPlan(self.x.shape[0], self.meta_path_edge_index_list,
+                                           self_loops=self.kind in ('gat', 'gcn'), shard_rank=self._shard[0],
+                                           shard_world=self._shard[1], shard_tile=self._shard[2],
+                                           gather_row_bytes=4 * hidden * (heads if self.kind == 'gat' else 1),
+                                           with_reverse=single)       # reversed relations drive the backward gathers
+        attr = '_train_engine' if train else '_engine'
+        if getattr(self, attr) is None:
+            if train and not single:
+                raise NotImplementedError('the backward pass is single-GPU for now')
+            setattr(self, attr, _engine.PEAEngine(self._plan, self.kind, self.meta_path_steps, emb, hidden, repr_dim,
+                                                  heads=heads if self.kind == 'gat' else 1,
+                                                  channel_aggr=self.channel_aggr, gcn_deg_from=self.gcn_deg_from,
+                                                  enable_backward=train))
+        return getattr(self, attr)
 
     def _layer_params(self):
         slots = _engine.PARAM_SLOTS[self.kind]
@@ -170,10 +182,32 @@ class PEABaseRecsysModel(GraphRecsysModel):
             for layer in channel.gnn_layers:
                 if self.training and getattr(layer, 'dropout', 0) > 0:
                     raise NotImplementedError('attention dropout > 0 is not implemented (p = 0 in every reference script)')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(metapath_idx, return_stack)
         eng = self._get_engine()
         return eng.forward(self._layer_params(), self.x.detach(), getattr(self, 'att', None), masked=metapath_idx,
                            want_stack=return_stack)
 
+    def _forward_autograd(self, metapath_idx, return_stack):
+        """Differentiable forward: conv stack forward + backward in HIP, fusion (models/base.py:194-203) in torch ops."""
+        eng = self._get_engine(train=True)
+        flat = [t for lp in self._layer_params() for t in lp]
+        stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
+        x = stack
+        if metapath_idx is not None:
+            keep = torch.ones(x.shape[1], dtype=x.dtype, device=x.device)
+            keep[metapath_idx] = 0
+            x = x * keep.view(1, -1, 1)
+        if self.channel_aggr == 'mean':
+            out = x.mean(dim=1)
+        else:
+            atts = torch.softmax(torch.sum(x * self.att, dim=-1), dim=-1).unsqueeze(-1)
+            out = torch.sum(x * atts, dim=1)
+        return (out, stack) if return_stack else out
+
     def predict(self, unids, inids):
+        if self.cached_repr.requires_grad:
+            z = torch.cat([self.cached_repr[unids], self.cached_repr[inids]], dim=-1)
+            return self.fc2(torch.relu(self.fc1(z)))
         return _engine.predict(self.cached_repr, unids, inids, self.fc1.weight, self.fc1.bias, self.fc2.weight,
                                self.fc2.bias)

@@ -144,9 +144,6 @@ def test_error_behaviour():
     model.eval()
     with pytest.raises(IndexError):
         model.predict(torch.tensor([0]).cuda(), torch.tensor([10 ** 6]).cuda())
-    model.train()
-    with pytest.raises(NotImplementedError):          # forward-only so far: fail loudly, never silently
-        model.loss(torch.from_numpy(g.batch).cuda())
     with pytest.raises(NotImplementedError):
         build_model('gat', g.meta['num_nodes'], g.edges, g.steps, 32, 24, 16, channel_aggr='concat').eval()
 
