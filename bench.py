@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--scale', type=float, default=1.0, help='edge/node count multiplier (tests only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event roofline leg')
+    ap.add_argument('--train-steps', type=int, default=0, help='also time this many full training steps '
+                    '(zero_grad, loss, backward, Adam step: reference solvers.py:213-216); extra field, N=1 only')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' "
                     'only to rehearse several ranks on one GPU)')
     return ap.parse_args()
@@ -221,6 +223,33 @@ def main():
                            'algorithmic_bytes_per_launch': units / launches}
         out['kernels_ms_per_step'] = {k: round(v[1] / args.steps, 4) for k, v in
                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    if world == 1 and args.train_steps > 0:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+
+        def train_step():
+            opt.zero_grad()
+            l = model.loss(batch)
+            l.backward()
+            opt.step()
+            return l
+
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            l = train_step()
+        torch.cuda.synchronize()
+        tt = (time.perf_counter() - t0) / args.train_steps
+        out['training_step'] = {'ms_per_step': tt * 1e3, 'steps': args.train_steps, 'loss': float(l),
+                                'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step'}
+        if profile:
+            lib.pea_profile_enable(1)
+            train_step()
+            torch.cuda.synchronize()
+            lib.pea_profile_enable(0)
+            out['training_step']['hip_kernels_ms'] = {k: round(v[1], 3) for k, v in
+                                                      sorted(read_profile().items(), key=lambda kv: -kv[1][1])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, want = cpu_baseline(dataset, model, args.kind)
         out['cpu_baseline'] = base

@@ -327,16 +327,25 @@ int launch_bwd_mode(const AggLaunch &base, hipStream_t stream) {
     return PEA_OK;
 }
 
-// out[c] = sum_n A[n, c] * (S ? S[n, c / F] : 1) for c < W, rows in a fixed order (two stages, no atomics)
+// out[c] = sum_n A[n, c] * (S ? S[n, c / F] : 1) for c < W, rows in a fixed order (two stages, no atomics).
+// Stage 1: block b owns a contiguous row chunk; its 256 threads are 4 row lanes x 64 columns (256-byte coalesced
+// row pieces), partial sums of the 4 row lanes are folded through LDS in lane order.
 __global__ __launch_bounds__(256) void colsum_stage1(int64_t N, int W, int F, const float *__restrict__ A, int lda,
                                                      const float *__restrict__ S, int lds, float *__restrict__ part) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= W) return;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(N, r0 + rows_per);
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += A[r * lda + c] * (S ? S[r * lds + c / F] : 1.f);
-    part[(size_t)blockIdx.x * W + c] = s;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+        const int c = c0 + cl;
+        float s = 0.f;
+        if (c < W)
+            for (int64_t r = r0 + rl; r < r1; r += 4) s += A[r * lda + c] * (S ? S[r * lds + c / F] : 1.f);
+        red[rl][cl] = s;
+        __syncthreads();
+        if (rl == 0 && c < W) part[(size_t)blockIdx.x * W + c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void colsum_stage2(int nparts, int W, const float *__restrict__ part, float scale,
@@ -378,8 +387,7 @@ int launch_colsum(int64_t N, int W, int F, const float *A, int lda, const float 
                   float *out, hipStream_t stream) {
     if (W <= 0) return PEA_OK;
     ProfScope ps("colsum", stream, 0.0);
-    dim3 grid(kColsumParts, (unsigned)((W + 255) / 256));
-    hipLaunchKernelGGL(colsum_stage1, grid, dim3(256), 0, stream, N, W, F, A, lda, S, lds, part);
+    hipLaunchKernelGGL(colsum_stage1, dim3(kColsumParts), dim3(256), 0, stream, N, W, F, A, lda, S, lds, part);
     hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, kColsumParts, W, part, scale, out);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
