@@ -1,0 +1,93 @@
+"""GPU: edge cases of the path -- empty and degenerate relations, tiny graphs, every lane-group width, error codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_fp32_close, build_model, f64_forward, random_state_dict
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _check(kind, n, edges, steps, emb, hidden, repr_dim, heads=1, aggr='att', seed=3):
+    model = build_model(kind, n, edges, steps, emb, hidden, repr_dim, heads=heads, channel_aggr=aggr)
+    model.load_state_dict(random_state_dict(model, seed))
+    model.eval()
+    with torch.no_grad():
+        fused, stack = model.forward(return_stack=True)
+    sd = {k: _np(v) for k, v in model.state_dict().items()}
+    cps, hls = [], []
+    for p, S in enumerate(steps):
+        cps.append([{k[len('pea_channels.%d.gnn_layers.%d.' % (p, s)):]: v for k, v in sd.items()
+                     if k.startswith('pea_channels.%d.gnn_layers.%d.' % (p, s))} for s in range(S)])
+        hls.append([1] * S if kind != 'gat' else ([heads] * (S - 1) + [1] if S > 1 else [heads]))
+    want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, hls, att=sd.get('att'), channel_aggr=aggr, return_stack=True)
+    t_fused, t_stack = f64_forward(kind, sd, edges, steps, heads, aggr)
+    assert_fp32_close(_np(stack), wstack, t_stack, what='stack')
+    assert_fp32_close(_np(fused), want, t_fused, what='fused')
+    return model
+
+
+@pytest.mark.parametrize('kind', ['gat', 'gcn', 'sage'])
+def test_empty_and_self_loop_only_relations(kind):
+    n = 37
+    rng = np.random.default_rng(0)
+    empty = np.zeros((2, 0), np.int64)
+    loops = np.stack([np.arange(10), np.arange(10)]).astype(np.int64)        # only self loops (dropped by GAT/GCN)
+    some = np.stack([rng.integers(0, n, 90), rng.integers(0, n, 90)]).astype(np.int64)
+    _check(kind, n, [[empty, some], [loops, empty], [some, loops]], [2, 2, 2], 16, 8, 8)
+
+
+@pytest.mark.parametrize('kind', ['gat', 'gcn', 'sage'])
+def test_tiny_graph_and_one_step_channels(kind):
+    ei = np.array([[0, 1, 2, 2, 4], [1, 0, 0, 3, 4]], np.int64)
+    _check(kind, 5, [[ei], [np.ascontiguousarray(ei[::-1])]], [1, 1], 8, 8, 4)
+
+
+@pytest.mark.parametrize('emb,hidden,repr_dim,heads', [(4, 4, 4, 1), (8, 12, 8, 1), (128, 128, 16, 1), (64, 256, 16, 1),
+                                                       (16, 8, 4, 4), (32, 64, 16, 4)])
+def test_every_lane_group_width(emb, hidden, repr_dim, heads):
+    """G = 4 ... 64 lanes per row chunk, head widths 4 ... 256 (incl. non-power-of-two 12), up to 4 heads."""
+    rng = np.random.default_rng(1)
+    n = 300
+    a = np.stack([rng.integers(0, n, 4000), rng.integers(0, 40, 4000)]).astype(np.int64)   # 40 hot destinations
+    b = np.ascontiguousarray(a[::-1])
+    for kind in ('gat', 'sage'):
+        _check(kind, n, [[a, b], [b, a], [a, b]], [2, 2, 2], emb, hidden, repr_dim, heads=heads if kind == 'gat' else 1)
+
+
+def test_error_codes_and_messages():
+    from graph_recsys_benchmark_amd import _lib
+    from graph_recsys_benchmark_amd.engine import GraphPlan, PEAEngine
+    lib = _lib.load()
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]], dtype=torch.int64).cuda()
+    plan = GraphPlan(4, [[ei, ei]], True)
+    with pytest.raises(_lib.PeaError) as e:            # widths must be multiples of 4
+        PEAEngine(plan, 'gat', [2], 6, 8, 4)
+    assert e.value.code == -1 and 'multiples of 4' in str(e.value)
+    eng = PEAEngine(plan, 'gat', [2], 8, 8, 4)
+    x = torch.zeros(4, 8, device='cuda')
+    params = [(torch.zeros(8, 8, device='cuda'), torch.zeros(1, 1, 8, device='cuda'), torch.zeros(1, 1, 8, device='cuda'),
+               torch.zeros(8, device='cuda')),
+              (torch.zeros(4, 8, device='cuda'), torch.zeros(1, 1, 4, device='cuda'), torch.zeros(1, 1, 4, device='cuda'),
+               torch.zeros(4, device='cuda'))]
+    out = eng.forward(params, x, att=torch.zeros(1, 1, 4, device='cuda'))
+    assert out.shape == (4, 4) and torch.isfinite(out).all()
+    with pytest.raises(_lib.PeaError):                  # masked channel out of range
+        eng.forward(params, x, att=torch.zeros(1, 1, 4, device='cuda'), masked=3)
+    ptrs = (C.c_void_p * 8)()
+    rc = lib.pea_model_forward(eng._h, ptrs, _lib.ptr(x), None, -1, _lib.ptr(eng._ws), 16, _lib.ptr(out), None, None)
+    assert rc == -4 and b'workspace' in lib.pea_last_error()      # PEA_ERR_NOMEM
+    rc = lib.pea_model_forward(eng._h, ptrs, _lib.ptr(x), _lib.ptr(x), -1, _lib.ptr(eng._ws), eng.workspace_bytes,
+                               _lib.ptr(out), None, None)
+    assert rc == -1 and b'null weight' in lib.pea_last_error()    # null parameter pointer
+    with pytest.raises(ValueError):
+        GraphPlan(4, [[ei.to(torch.int32)]], True)
+    with pytest.raises(RuntimeError):
+        GraphPlan(4, [[ei.cpu()]], True)
