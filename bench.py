@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event roofline leg')
     ap.add_argument('--train-steps', type=int, default=0, help='also time this many full training steps '
                     '(zero_grad, loss, backward, Adam step: reference solvers.py:213-216); extra field, N=1 only')
+    ap.add_argument('--emulate-world', type=int, default=0, help='single process: time ONE rank (rank 0) of a sharded run of\n'
+                    'this many ranks with the collectives skipped (results are wrong, timings are per-rank compute + host work)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' "
                     'only to rehearse several ranks on one GPU)')
     return ap.parse_args()
@@ -143,6 +145,9 @@ def main():
     batch = torch.from_numpy(dataset.bpr_batch()).to(device)
     if world > 1:
         model.shard(rank, world)     # destination rows tile-interleaved over the ranks; exchanges over RCCL
+    elif args.emulate_world > 1:
+        model.shard(0, args.emulate_world)
+        model._get_engine().plan.layout.dry = True
 
     def step():
         with torch.no_grad():

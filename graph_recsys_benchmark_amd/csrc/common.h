@@ -191,6 +191,10 @@ struct GemmJob {
     const float *bias;  // [n_out] or null (packed alongside B)
     int n_seg;
     GemmSegment seg[kMaxSegments];
+    // optional per-job row set (sharded first layer: each relation's transform covers its own row list); null = the
+    // row set of the launch
+    const int *rows;
+    int64_t n_rows;
 };
 int launch_gemm(const GemmJob &job, const int *rows, int64_t n_rows, hipStream_t stream);
 int launch_gemm_batch(const GemmJob *jobs, int n_jobs, const int *rows, int64_t n_rows, hipStream_t stream);

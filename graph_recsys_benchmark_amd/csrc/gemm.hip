@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmBatch Bt, cons
     __shared__ float Bs[2][2 * KH][32];
     constexpr int NLD = (2 * KH * 32 / 4) / 256;  // float4 loads per thread per B tile
     const GemmJob &J = Bt.j[blockIdx.y];
+    if (J.rows) {
+        rows = J.rows;
+        n_rows = J.n_rows;
+    }
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * 32;
     const int64_t grow = row0 + r;
@@ -153,6 +157,7 @@ struct PersistArgs {
     int item_start[kMaxBatch + 1]; // first item of job j
     int lds_off[kMaxBatch];        // float offset of job j's B image, row stride lds_ld[j]
     int lds_ld[kMaxBatch];
+    int n_tiles[kMaxBatch];        // 32-row tiles of job j (jobs may carry their own row lists)
 };
 
 extern __shared__ float g_lds[];
@@ -173,13 +178,17 @@ __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(cons
         }
     }
     __syncthreads();
-    const int n_tiles = (int)((n_rows + 31) / 32);
     const int stride = gridDim.x * NW;
+    const int *launch_rows = rows;
+    const int64_t launch_n_rows = n_rows;
     for (int item = blockIdx.x * NW + (tid >> 6); item < Pa.n_items; item += stride) {
         int j = 0;
         while (j + 1 < Bt.n && item >= Pa.item_start[j + 1]) ++j;
         const GemmJob &J = Bt.j[j];
+        const int *rows = J.rows ? J.rows : launch_rows;
+        const int64_t n_rows = J.rows ? J.n_rows : launch_n_rows;
         const int local = item - Pa.item_start[j];
+        const int n_tiles = Pa.n_tiles[j];
         const int tile = local % n_tiles, grp = local / n_tiles;  // consecutive waves -> consecutive row tiles
         const int64_t row0 = (int64_t)tile * 32, grow = row0 + r;
         const bool rv = grow < n_rows;
@@ -282,10 +291,11 @@ constexpr size_t kLdsBudget = 160 * 1024 - 1024;  // dynamic LDS a workgroup may
 template <int KH>
 int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double bytes, hipStream_t stream) {
     PersistArgs Pa;
-    const int n_tiles = (int)((n_rows + 31) / 32);
     int off = 0, items = 0;
     for (int j = 0; j < Bt.n; ++j) {
         const int nct = (Bt.j[j].n_out + 31) / 32;
+        const int n_tiles = (int)(((Bt.j[j].rows ? Bt.j[j].n_rows : n_rows) + 31) / 32);
+        Pa.n_tiles[j] = n_tiles;
         Pa.lds_ld[j] = nct * 32;
         Pa.lds_off[j] = off;
         off += 2 * KH * Pa.lds_ld[j];
@@ -321,11 +331,12 @@ int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double 
 // Jobs of one call share the row set; jobs with the same k-depth class go out as one launch.  A job whose B does
 // not fit the LDS budget is cut into column chunks; k deeper than 128 falls back to the staged kernel.
 int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, int64_t n_rows, hipStream_t stream) {
-    if (n_rows <= 0 || n_jobs_in <= 0) return PEA_OK;
+    if (n_jobs_in <= 0) return PEA_OK;
     std::vector<GemmJob> jobs;
     for (int i = 0; i < n_jobs_in; ++i) {
         PEA_TRY(check_job(jobs_in[i]));
         const GemmJob &J = jobs_in[i];
+        if ((J.rows ? J.n_rows : n_rows) <= 0) continue;
         const int K = J.K1 + J.K2;
         const int KH = K <= 32 ? 16 : K <= 64 ? 32 : 64;
         const int max_cols = (int)(kLdsBudget / sizeof(float) / (size_t)(2 * KH)) / 32 * 32;
@@ -370,7 +381,9 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                         default: rc = launch_persist<64>(Bt, rows, n_rows, bytes, stream); break;
                     }
                 } else {
-                    dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)Bt.n);
+                    int64_t max_rows = n_rows;
+                    for (int q = 0; q < Bt.n; ++q) max_rows = std::max<int64_t>(max_rows, Bt.j[q].rows ? Bt.j[q].n_rows : 0);
+                    dim3 grid((unsigned)((max_rows + 127) / 128), (unsigned)Bt.n);
                     ProfScope ps("gemm_mfma_deep", stream, bytes);
                     hipLaunchKernelGGL(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows);
                     if (hipGetLastError() != hipSuccess) rc = PEA_ERR_HIP;
@@ -388,7 +401,7 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                 if (!deep && Bt.n > 0 && lds + need > kLdsBudget) PEA_TRY(flush());
                 Bt.j[Bt.n++] = jobs[i];
                 lds += need;
-                bytes += 4.0 * (double)n_rows * (K + jobs[i].n_out);
+                bytes += 4.0 * (double)(jobs[i].rows ? jobs[i].n_rows : n_rows) * (K + jobs[i].n_out);
                 if (Bt.n == kMaxBatch) PEA_TRY(flush());
             }
             PEA_TRY(flush());

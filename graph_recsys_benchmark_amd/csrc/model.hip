@@ -557,6 +557,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         if (L.shared_input) {
             // sharded level 0: x is replicated, so each rank transforms, per relation, exactly the rows it will
             // read: its own rows plus that relation's source nodes (plan need_rows)
+            std::vector<GemmJob> rel_jobs;
             size_t i = 0;
             while (i < L.units.size()) {
                 size_t j = i;
@@ -576,9 +577,12 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 J.seg[0].c1 = c_end - c_beg;
                 J.seg[0].dst = T + c_beg;
                 J.seg[0].ld = L.ld_t;
-                PEA_TRY(launch_gemm(J, R.need_rows, R.n_need, stream));
+                J.rows = R.need_rows;       // one launch for all relations, each job with its own row list
+                J.n_rows = R.n_need;
+                rel_jobs.push_back(J);
                 i = j;
             }
+            PEA_TRY(launch_gemm_batch(rel_jobs.data(), (int)rel_jobs.size(), nullptr, 0, stream));
             return PEA_OK;
         }
         std::vector<GemmJob> jobs;

@@ -50,6 +50,7 @@ class ShardLayout:
         self.num_nodes, self.rank, self.world, self.tile = int(num_nodes), int(rank), int(world), int(tile)
         self._owned = {}
         self._gather_plan = {}
+        self.dry = False   # True: skip the collectives (single-process rehearsal of one rank's compute + host work)
 
     def owner(self, nodes):
         return torch.div(nodes, self.tile, rounding_mode='floor') % self.world
@@ -71,7 +72,7 @@ class ShardLayout:
     # ---------------------------------------------------------------- collectives
     def _all_gather_blocks(self, buf, block_rows, group=None):
         """buf: contiguous [world * block_rows, ld]; block `rank` holds this rank's rows, the others are filled in."""
-        if self.world == 1 or block_rows == 0:
+        if self.world == 1 or block_rows == 0 or self.dry:
             return
         mine = buf[self.rank * block_rows:(self.rank + 1) * block_rows]
         if dist.get_backend(group) == 'nccl':
