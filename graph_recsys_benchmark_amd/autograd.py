@@ -116,27 +116,41 @@ def backward_conv_stack(engine, d_stack, x, layer_params):
                     dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] += dagg[:, u['t_col']:u['t_col'] + u['in_w']]
             continue
         level_call(s, 0)
-        for u in lv['units']:
+        units = lv['units']
+        if s == 0:
+            # every first-layer channel reads x: one GEMM for all weight gradients, one for dx
+            ncol = units[-1]['t_col'] + units[-1]['HF']
+            dT0 = dT[:, :ncol]
+            if kind == 'gat':
+                dW_all = dT0.t() @ x                                        # [sum HF, emb]
+                w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=0)
+                dx += dT0 @ w_cat
+            else:
+                dW_all = x.t() @ dT0                                        # [emb, sum F]
+                w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=1)
+                dx += dT0 @ w_cat.t()
+        for u in units:
             li = first[u['p']] + u['s']
             dTu = dT[:, u['t_col']:u['t_col'] + u['HF']]
-            In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
             if kind == 'gat':
-                w = layer_params[li][0]                                     # lin.weight [HF, in]
-                grads[li][0] = dTu.t() @ In
-                dIn = dTu @ w
+                if s == 0:
+                    grads[li][0] = dW_all[u['t_col']:u['t_col'] + u['HF']]
+                else:
+                    In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
+                    grads[li][0] = dTu.t() @ In
+                    dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = dTu @ layer_params[li][0]
                 shape = layer_params[li][1].shape
                 grads[li][1] = gpack[lv['att_dst_off'] + u['t_col']:lv['att_dst_off'] + u['t_col'] + u['HF']].clone().view(shape)
                 grads[li][2] = gpack[lv['att_src_off'] + u['t_col']:lv['att_src_off'] + u['t_col'] + u['HF']].clone().view(shape)
                 grads[li][3] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
             else:
-                w = layer_params[li][0]                                     # weight [in, F]
-                grads[li][0] = In.t() @ dTu
-                dIn = dTu @ w.t()
+                if s == 0:
+                    grads[li][0] = dW_all[:, u['t_col']:u['t_col'] + u['HF']]
+                else:
+                    In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
+                    grads[li][0] = In.t() @ dTu
+                    dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = dTu @ layer_params[li][0].t()
                 grads[li][1] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
-            if s == 0:
-                dx += dIn
-            else:
-                dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = dIn
     return dx, grads
 
 

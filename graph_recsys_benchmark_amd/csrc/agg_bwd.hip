@@ -339,8 +339,21 @@ __global__ __launch_bounds__(256) void colsum_stage1(int64_t N, int W, int F, co
     for (int c0 = 0; c0 < W; c0 += 64) {
         const int c = c0 + cl;
         float s = 0.f;
-        if (c < W)
-            for (int64_t r = r0 + rl; r < r1; r += 4) s += A[r * lda + c] * (S ? S[r * lds + c / F] : 1.f);
+        if (c < W) {
+            // 8 independent loads in flight per lane (fixed summation tree: 8 strided partial sums, then in order)
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int k = c / F;
+            int64_t r = r0 + rl;
+            for (; r + 28 < r1; r += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t rr = r + 4 * u;
+                    acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
+                }
+            }
+            for (; r < r1; r += 4) acc[0] += A[r * lda + c] * (S ? S[r * lds + k] : 1.f);
+            s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
         red[rl][cl] = s;
         __syncthreads();
         if (rl == 0 && c < W) part[(size_t)blockIdx.x * W + c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];

@@ -124,7 +124,6 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         const float *Out = g.last ? X + g.out_col : O + g.out_col;
         const int ldg = g.last ? m->ld_x : L.ld_o;
         if (!g.last) PEA_TRY(launch_relu_mask(N, g.W, G, ldg, Out, ldg, stream));
-        PEA_TRY(launch_colsum(N, g.W, g.W, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + g.bias_off, stream));
         AggGroup a{};
         a.W = g.W;
         a.F = g.F;
@@ -179,11 +178,27 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         S.out = dT + g.col;
         S.ld_out = L.ld_t;
         PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, &S, 1, stream));
-        // d att_j[c] = sum_n d a_src[n, head(c)] T[n, c],  d att_i likewise with d a_dst
-        PEA_TRY(launch_colsum(N, g.W, g.F, T + g.col, L.ld_t, wsf + L.off_das + g.a_k, L.ld_k, 1.0f, colsum_part,
-                              gpack + L.att_src_off + g.col, stream));
-        PEA_TRY(launch_colsum(N, g.W, g.F, T + g.col, L.ld_t, wsf + L.off_dad + g.a_k, L.ld_k, 1.0f, colsum_part,
-                              gpack + L.att_dst_off + g.col, stream));
+    }
+    // Gradient reductions, one launch per run of groups whose columns (and heads) are contiguous:
+    //   d bias[c] = sum_n g[n, c];   d att_j[c] = sum_n d a_src[n, head(c)] T[n, c];   d att_i likewise with d a_dst
+    size_t gi = 0;
+    while (gi < L.groups.size()) {
+        const GroupPlan &g0 = L.groups[gi];
+        size_t gj = gi + 1;
+        int W = g0.W;
+        while (gj < L.groups.size() && L.groups[gj].last == g0.last && L.groups[gj].F == g0.F &&
+               L.groups[gj].col == g0.col + W && L.groups[gj].out_col == g0.out_col + W)
+            W += L.groups[gj++].W;
+        float *G = g0.last ? dX + g0.out_col : dO + g0.out_col;
+        const int ldg = g0.last ? m->ld_x : L.ld_o;
+        PEA_TRY(launch_colsum(N, W, W, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + g0.bias_off, stream));
+        if (d.kind == PEA_KIND_GAT) {
+            PEA_TRY(launch_colsum(N, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_das + g0.a_k, L.ld_k, 1.0f, colsum_part,
+                                  gpack + L.att_src_off + g0.col, stream));
+            PEA_TRY(launch_colsum(N, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_dad + g0.a_k, L.ld_k, 1.0f, colsum_part,
+                                  gpack + L.att_dst_off + g0.col, stream));
+        }
+        gi = gj;
     }
     return PEA_OK;
 }
