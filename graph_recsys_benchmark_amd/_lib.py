@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libpeahip.so')
 PEA_OK = 0
 KIND_GAT, KIND_GCN, KIND_SAGE = 0, 1, 2
 PLAN_SELF_LOOPS = 1
+PLAN_EDGE_IDS = 2
 FUSE_ATT, FUSE_MEAN = 0, 1
 
 _ERR_NAMES = {-1: 'bad argument', -2: 'id out of range', -3: 'HIP runtime error', -4: 'workspace too small',
@@ -67,6 +68,8 @@ SIGNATURES = {
     'pea_gat_conv': (_int, [_vp, _int, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, C.c_float, _int, _vp, _i64, _vp, _sz, _vp]),
     'pea_gcn_conv': (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _int, _int, _vp, _i64, _vp, _sz, _vp]),
     'pea_sage_conv': (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _int, _vp, _i64, _vp, _sz, _vp]),
+    'pea_weighted_aggregate_workspace_bytes': (_sz, [_vp, _int, _int]),
+    'pea_weighted_aggregate': (_int, [_vp, _int, _int, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp]),
     'pea_fuse': (_int, [_i64, _int, _int, _vp, _i64, C.POINTER(_int), _vp, _int, _int, _vp, _vp]),
     'pea_bpr_workspace_bytes': (_sz, [_i64]),
     'pea_bpr_score': (_int, [_i64, _int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -31,7 +31,7 @@ __device__ __forceinline__ void finish_row(const AggGroup &P, int row, int c4, i
             sp[0] = st.m;
             sp[1] = st.s;
         }
-    } else if (MODE == AGG_GCN) {
+    } else if (MODE == AGG_GCN || MODE == AGG_WSUM) {
         o = sum;
     } else {
         const float inv = 1.0f / (float)(deg < 1 ? 1 : deg);
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
             if (ok) st.push(leaky(a + a_d, P.neg_slope), h);
         } else if (MODE == AGG_GCN) {
             sum = fma4(P.dinv[j] * di, h, sum);
+        } else if (MODE == AGG_WSUM) {
+            sum = fma4(P.edge_w[P.eid[e]], h, sum);
         } else {
             sum = add4(sum, h);
         }
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
             for (int u = 0; u < U; ++u) {
                 h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
                 if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
+                if (MODE == AGG_WSUM) a[u] = ok[u] ? P.edge_w[P.eid[base + t + u * NSG + sub]] : 0.f;
             }
             if (MODE == AGG_GAT) {
 #pragma unroll
@@ -193,6 +196,8 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
                 for (int u = 0; u < U; ++u) {
                     if (MODE == AGG_GCN) {
                         sum = fma4(ok[u] ? a[u] * di : 0.f, h[u], sum);
+                    } else if (MODE == AGG_WSUM) {
+                        sum = fma4(a[u], h[u], sum);
                     } else {
                         if (ok[u]) sum = add4(sum, h[u]);
                     }
@@ -308,7 +313,7 @@ const char *kname(int which) {
     static bool init = false;
     if (!init) {
         const char *w[3] = {"short", "long", "merge"};
-        const char *m = MODE == AGG_GAT ? "gat" : MODE == AGG_GCN ? "gcn" : "mean";
+        const char *m = MODE == AGG_GAT ? "gat" : MODE == AGG_GCN ? "gcn" : MODE == AGG_WSUM ? "wsum" : "mean";
         for (int i = 0; i < 3; ++i) snprintf(names[i], sizeof(names[i]), "agg_%s_g%d_%s", w[i], G, m);
         init = true;
     }
@@ -440,6 +445,7 @@ int launch_aggregate(AggMode mode, const AggGroup *groups, int n_groups, hipStre
     switch (mode) {
         case AGG_GAT: return launch_mode<AGG_GAT>(base, stream);
         case AGG_GCN: return launch_mode<AGG_GCN>(base, stream);
+        case AGG_WSUM: return launch_mode<AGG_WSUM>(base, stream);
         default: return launch_mode<AGG_MEAN>(base, stream);
     }
 }

@@ -72,6 +72,7 @@ struct Relation {
     int max_deg = 0;
     int *rowptr = nullptr;  // device [N+1]
     int *col = nullptr;     // device [e_kept] source ids, destination-sorted, stable
+    int *eid = nullptr;     // device [e_kept] original COO edge index of each CSR slot (PEA_PLAN_EDGE_IDS)
     float *dinv_row = nullptr, *dinv_col = nullptr;  // device [N], GCN deg^-1/2 (lazy)
     float *invdeg = nullptr;                         // device [N], 1 / max(in-degree, 1) (SAGE backward, lazy)
     // work lists (device), restricted to the rows this rank owns
@@ -116,7 +117,7 @@ int ensure_dinv_slots(pea_plan *plan, int rel, bool from_col, hipStream_t stream
 // AGG_GAT_BWD_D / _S: the two gather passes of the GAT backward (agg.hip): D walks a destination row's in-edges
 // (gathers T_j) and yields d a_dst; S walks a source row's out-edges over the REVERSED relation (gathers the output
 // gradient rows g_i) and yields dT_j and d a_src.
-enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2, AGG_GAT_BWD_D = 3, AGG_GAT_BWD_S = 4 };
+enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2, AGG_GAT_BWD_D = 3, AGG_GAT_BWD_S = 4, AGG_WSUM = 5 };
 
 // One horizontal group: C channel-heads of width F that share a relation, columns contiguous.
 struct AggGroup {
@@ -130,6 +131,8 @@ struct AggGroup {
     const float *feat_self;  // the destination node's own row (self loop, a_dst), indexed by node id, stride ld_self
     const float *att_src;  // GAT: att_j flattened over the group's columns [W] (multiplies the SOURCE row)
     const float *att_dst;  // GAT: att_i flattened [W] (multiplies the TARGET row)
+    const int *eid;          // AGG_WSUM: original edge index of each CSR slot
+    const float *edge_w;     // AGG_WSUM: per-edge weight in the caller's COO order (KGAT/KGCN att_map, NGCF coefficient)
     const float *dinv;   // GCN deg^-1/2 indexed like `col`
     const float *dinv_self;  // GCN deg^-1/2 indexed by node id
     const float *bias;   // [W] or null

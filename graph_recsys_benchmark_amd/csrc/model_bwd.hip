@@ -226,3 +226,51 @@ extern "C" int pea_model_describe(const pea_model *m, int64_t *out, int max_len,
     if (out && max_len >= (int)v.size()) std::copy(v.begin(), v.end(), out);
     return PEA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weighted neighbour sum with caller-supplied per-edge weights (the message/aggregate half of the reference's own
+// baseline convs: graph_recsys_benchmark/nn/kgat_conv.py:36-44, nn/kgcn_conv.py:32-37 `x_j * att_map`, and
+// nn/ngcf_conv.py:42-45 with coff folded to a per-edge weight):   out_i = sum_{e: j -> i} w_e x_j.
+// The plan must have been created with PEA_PLAN_EDGE_IDS (weights are in the caller's COO order).
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t pea_weighted_aggregate_workspace_bytes(const pea_plan *plan, int relation, int width) {
+    if (!plan || relation < 0 || relation >= (int)plan->rels.size() || width <= 0) return 0;
+    size_t fl = 0;
+    for (int c = 0; c < width; c += 256) fl += (size_t)plan->rels[(size_t)relation].n_slots * partial_record_floats(std::min(256, width - c), std::min(256, width - c));
+    return fl * sizeof(float) + 512;
+}
+
+extern "C" int pea_weighted_aggregate(const pea_plan *plan, int relation, int width, const float *x, int64_t ldx,
+                                      const float *edge_weight, float *out, int64_t ldo, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    PEA_REQUIRE(plan && relation >= 0 && relation < (int)plan->rels.size(), PEA_ERR_ARG, "weighted_aggregate: bad relation");
+    const Relation &R = plan->rels[(size_t)relation];
+    PEA_REQUIRE(R.eid != nullptr || R.e_kept == 0, PEA_ERR_ARG, "weighted_aggregate: the plan was created without PEA_PLAN_EDGE_IDS");
+    PEA_REQUIRE(x && out && (edge_weight || R.e_kept == 0), PEA_ERR_ARG, "weighted_aggregate: null argument");
+    PEA_REQUIRE(width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= width && ldo >= width, PEA_ERR_ARG,
+                "weighted_aggregate: width %d and row strides must be multiples of 4", width);
+    PEA_REQUIRE(workspace_bytes >= pea_weighted_aggregate_workspace_bytes(plan, relation, width), PEA_ERR_NOMEM,
+                "weighted_aggregate: workspace too small");
+    float *partial = aligned_ws(workspace);
+    std::vector<AggGroup> gs;
+    for (int c = 0; c < width; c += 256) {
+        AggGroup a{};
+        fill_lists(a, R);
+        a.eid = R.eid;
+        a.edge_w = edge_weight;
+        a.W = std::min(256, width - c);
+        a.F = a.W;
+        a.feat = x + c;
+        a.ld_feat = (int)ldx;
+        a.feat_self = a.feat;
+        a.ld_self = (int)ldx;
+        a.out = out + c;
+        a.ld_out = (int)ldo;
+        a.partial = partial;
+        partial += (size_t)R.n_slots * partial_record_floats(a.W, a.F);
+        gs.push_back(a);
+    }
+    for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+        PEA_TRY(launch_aggregate(AGG_WSUM, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), (hipStream_t)stream));
+    return PEA_OK;
+}

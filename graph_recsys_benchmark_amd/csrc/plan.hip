@@ -106,6 +106,16 @@ __global__ void rowptr_from_sorted(int64_t E, int64_t N, const int *__restrict__
     rowptr[i] = (int)lo;
 }
 
+__global__ void iota_kernel(int64_t n, int *p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int)i;
+}
+
+__global__ void gather_src(int64_t n, const int *__restrict__ eid, const int *__restrict__ src, int *__restrict__ col) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) col[i] = src[eid[i]];
+}
+
 __global__ void count_sources(int64_t E, const int *__restrict__ col, int *__restrict__ cnt) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) atomicAdd(&cnt[col[e]], 1);
@@ -137,15 +147,15 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     PEA_HIP(hipMalloc((void **)&R.rowptr, (size_t)(N + 1) * sizeof(int)));
     int *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *err = nullptr;
     unsigned long long *k64_in = nullptr, *k64_out = nullptr;
-    int *hub_dev = nullptr, *bounds_dev = nullptr;
+    int *hub_dev = nullptr, *bounds_dev = nullptr, *ids_in = nullptr;
     int S = 1;  // source slices (1 = edge order inside a row is plain COO order)
     void *tmp = nullptr;
     int rc = PEA_OK;
     const size_t eb = (size_t)std::max<int64_t>(E, 1) * sizeof(int);
     auto cleanup = [&]() {
         (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(vals_in); (void)hipFree(err); (void)hipFree(tmp);
-        (void)hipFree(k64_in); (void)hipFree(k64_out); (void)hipFree(hub_dev); (void)hipFree(bounds_dev);
-        keys_in = keys_out = vals_in = err = hub_dev = bounds_dev = nullptr;
+        (void)hipFree(k64_in); (void)hipFree(k64_out); (void)hipFree(hub_dev); (void)hipFree(bounds_dev); (void)hipFree(ids_in);
+        keys_in = keys_out = vals_in = err = hub_dev = bounds_dev = ids_in = nullptr;
         k64_in = k64_out = nullptr;
         tmp = nullptr;
     };
@@ -195,12 +205,22 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
                 }
             }
         }
+        // with PEA_PLAN_EDGE_IDS the sort carries the ORIGINAL edge index (per-edge weights stay in COO order); the
+        // source ids are gathered through it afterwards
+        int *sort_vals = vals_in, *sort_out = R.col;
+        if (plan->flags & PEA_PLAN_EDGE_IDS) {
+            PEA_HIP_C(hipMalloc((void **)&ids_in, eb));
+            PEA_HIP_C(hipMalloc((void **)&R.eid, eb));
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, E, ids_in);
+            sort_vals = ids_in;
+            sort_out = R.eid;
+        }
         size_t tmp_bytes = 0;
         if (S == 1) {
-            PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
+            PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, sort_vals, sort_out, (size_t)E, 0u,
                                                 (unsigned)bits, stream));
             PEA_HIP_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-            PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, R.col, (size_t)E, 0u,
+            PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, sort_vals, sort_out, (size_t)E, 0u,
                                                 (unsigned)bits, stream));
         } else {
             PEA_HIP_C(hipMalloc((void **)&k64_in, (size_t)E * sizeof(unsigned long long)));
@@ -210,11 +230,15 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
             PEA_HIP_C(hipGetLastError());
             int sbits = 1;
             while ((1 << sbits) < S) ++sbits;
-            PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k64_in, k64_out, vals_in, R.col, (size_t)E, 0u,
+            PEA_HIP_C(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k64_in, k64_out, sort_vals, sort_out, (size_t)E, 0u,
                                                 (unsigned)(bits + sbits + 1), stream));
             PEA_HIP_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-            PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, k64_in, k64_out, vals_in, R.col, (size_t)E, 0u,
+            PEA_HIP_C(rocprim::radix_sort_pairs(tmp, tmp_bytes, k64_in, k64_out, sort_vals, sort_out, (size_t)E, 0u,
                                                 (unsigned)(bits + sbits + 1), stream));
+        }
+        if (plan->flags & PEA_PLAN_EDGE_IDS) {
+            hipLaunchKernelGGL(gather_src, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, E, R.eid, vals_in, R.col);
+            PEA_HIP_C(hipGetLastError());
         }
     }
     if (S == 1)
@@ -373,7 +397,7 @@ __global__ void scatter_to_slots(int64_t N, const int *__restrict__ slot_of_node
 void free_relation(Relation &R) {
     (void)hipFree(R.col_slot); (void)hipFree(R.dinv_row_slot); (void)hipFree(R.dinv_col_slot);
     (void)hipFree(R.slot_of_node); (void)hipFree(R.need_rows);
-    (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col); (void)hipFree(R.invdeg);
+    (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col); (void)hipFree(R.invdeg); (void)hipFree(R.eid);
     (void)hipFree(R.short_rows); (void)hipFree(R.long_items); (void)hipFree(R.deg0);
     (void)hipFree(R.hub_rows); (void)hipFree(R.hub_first); (void)hipFree(R.hub_count);
 }

@@ -55,6 +55,9 @@ extern "C" {
                                  add_self_loops; GCN: add_remaining_self_loops with unit weights).
                                  Leave clear for SAGE, which aggregates the edge list as given.   */
 
+#define PEA_PLAN_EDGE_IDS 2   /* also keep, per CSR slot, the index of the edge in the caller's COO (needed by
+                                 pea_weighted_aggregate, whose weights come in COO order)              */
+
 /* fusion modes (models/base.py:197-203; 'concat' is unusable in the reference, not offered) */
 #define PEA_FUSE_ATT 0
 #define PEA_FUSE_MEAN 1
@@ -195,6 +198,18 @@ int pea_gcn_conv(const pea_plan *plan, int relation, int in_channels, int out_ch
 int pea_sage_conv(const pea_plan *plan, int relation, int in_channels, int out_channels, const float *x,
                   int64_t ldx, const float *rel_weight, const float *rel_bias, const float *root_weight,
                   int relu, float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weighted neighbour sum with per-edge weights in the caller's COO order -- the message/aggregate half of the
+ * reference's own baseline convs (nn/kgat_conv.py:36-44, nn/kgcn_conv.py:32-37: x_j * att_map; nn/ngcf_conv.py:42-45
+ * with its degree coefficient folded into the weight):   out_i = sum_{e: j -> i} w_e x_j.
+ * x [N, width] stride ldx, out [N, width] stride ldo, edge_weight [num_edges of the relation].  The plan must carry
+ * PEA_PLAN_EDGE_IDS and, like those convs after remove_self_loops, no self loops are added.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pea_weighted_aggregate_workspace_bytes(const pea_plan *plan, int relation, int width);
+int pea_weighted_aggregate(const pea_plan *plan, int relation, int width, const float *x, int64_t ldx,
+                           const float *edge_weight, float *out, int64_t ldo, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fusion of the channel stack (models/base.py:196-203).

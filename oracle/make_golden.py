@@ -338,6 +338,45 @@ def make_sampling_and_metrics(mods):
           'HR@10 %.4f' % hr[5])
 
 
+def make_nn_convs():
+    """The reference's OWN conv classes (graph_recsys_benchmark/nn/{kgat,kgcn,ngcf}_conv.py) run for real; the only
+    foreign pieces are the MessagePassing base / remove_self_loops (restated, oracle/pyg_restatement.py)."""
+    conv = types.ModuleType('torch_geometric.nn.conv')
+    conv.MessagePassing = R.MessagePassing
+    utils = types.ModuleType('torch_geometric.utils')
+    utils.remove_self_loops = R.remove_self_loops
+    sys.modules.update({'torch_geometric.nn.conv': conv, 'torch_geometric.utils': utils})
+    nnp = types.ModuleType('graph_recsys_benchmark.nn')
+    nnp.__path__ = [os.path.join(REF, 'graph_recsys_benchmark', 'nn')]
+    sys.modules['graph_recsys_benchmark.nn'] = nnp
+    kgat = importlib.import_module('graph_recsys_benchmark.nn.kgat_conv').KGATConv
+    kgcn = importlib.import_module('graph_recsys_benchmark.nn.kgcn_conv').KGCNConv
+    ngcf = importlib.import_module('graph_recsys_benchmark.nn.ngcf_conv').NGCFConv
+    rng = np.random.default_rng(77)
+    n, e = 150, 1500
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    keep = src != dst
+    half = np.stack([src[keep], dst[keep]])
+    half = np.concatenate([half, np.stack([np.arange(1, n), np.zeros(n - 1, np.int64)])], axis=1)   # node 0 is a hub
+    ei = np.concatenate([half, half[::-1]], axis=1).astype(np.int64)            # both directions, like the KG
+    x = rng.normal(size=(n, 32)).astype(np.float32) * 0.3
+    att = rng.random(ei.shape[1]).astype(np.float32)
+    out = {'x': x, 'edge_index': ei, 'att_map': att}
+    torch.manual_seed(9)
+    eit, xt, attt = torch.from_numpy(ei), torch.from_numpy(x), torch.from_numpy(att)
+    for name, cls, args in (('kgat', kgat, (xt, eit, attt)), ('kgcn', kgcn, (xt, eit, attt)), ('ngcf', ngcf, (xt, eit))):
+        m = cls(32, 16)
+        with torch.no_grad():
+            for pn, p_ in m.named_parameters():
+                if pn == 'bias':
+                    p_.copy_(torch.randn_like(p_) * 0.1)
+            out[name + '/out'] = m(*args).numpy()
+        for pn, p_ in m.named_parameters():
+            out[name + '/param/' + pn] = p_.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'nn_convs.npz'), **out)
+    print('nn_convs.npz', {k: v.shape for k, v in out.items() if k.endswith('/out')})
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     mods = load_reference_models()
@@ -354,3 +393,4 @@ if __name__ == '__main__':
     make_rng_streams()
     make_checkpoint_manifest()
     make_sampling_and_metrics(mods)
+    make_nn_convs()

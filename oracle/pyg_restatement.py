@@ -182,3 +182,51 @@ class SAGEConv(torch.nn.Module):
         if self.normalize:
             out = F.normalize(out, p=2, dim=-1)
         return out
+
+
+def remove_self_loops(edge_index, edge_attr=None):
+    """torch_geometric.utils.remove_self_loops."""
+    mask = edge_index[0] != edge_index[1]
+    return edge_index[:, mask], (None if edge_attr is None else edge_attr[mask])
+
+
+class MessagePassing(torch.nn.Module):
+    """Minimal restatement of torch_geometric.nn.conv.MessagePassing (release 1.5.0, flow source_to_target) -- just
+    what the reference's own nn/{kgat,kgcn,ngcf}_conv.py use: propagate() gathers `<name>_j` / `<name>_i` views of
+    the tensors passed by keyword, hands `edge_index_i/_j` and other keyword arguments through by NAME to message(),
+    scatter-adds the messages over the target index, and calls update(aggr_out, <named kwargs>)."""
+
+    def __init__(self, aggr='add', flow='source_to_target', **kwargs):
+        super().__init__()
+        assert aggr == 'add' and flow == 'source_to_target'
+        self.aggr = aggr
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        import inspect
+        row, col = edge_index[0], edge_index[1]          # j = row (source), i = col (target)
+        n = None
+        for v in kwargs.values():
+            if torch.is_tensor(v) and v.dim() == 2:
+                n = v.size(0)
+                break
+
+        def collect(fn, skip):
+            args = []
+            for name in list(inspect.signature(fn).parameters)[skip:]:
+                if name.endswith('_j') and name[:-2] in kwargs:
+                    args.append(kwargs[name[:-2]].index_select(0, row))
+                elif name.endswith('_i') and name[:-2] in kwargs:
+                    args.append(kwargs[name[:-2]].index_select(0, col))
+                elif name == 'edge_index_i':
+                    args.append(col)
+                elif name == 'edge_index_j':
+                    args.append(row)
+                elif name == 'size_i':
+                    args.append(n)
+                else:
+                    args.append(kwargs[name])
+            return args
+
+        msg = self.message(*collect(self.message, 0))
+        out = scatter_add(msg, col, n)
+        return self.update(out, *collect(self.update, 1))
