@@ -65,6 +65,73 @@ __device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, 
     }
 }
 
+// Where column c of a job's output goes.  The job is wave-uniform, so the segment table is read with scalar loads and
+// the per-lane answer is a chain of selects (no memory wait in the epilogue).
+struct OutCol {
+    float *dst;
+    int ld, relu;
+};
+__device__ __forceinline__ OutCol find_out(const GemmJob &J, int c) {
+    OutCol o{nullptr, 0, 0};
+    for (int sg = 0; sg < J.n_seg; ++sg) {
+        const bool in = c >= J.seg[sg].c0 && c < J.seg[sg].c1;
+        o.dst = in ? J.seg[sg].dst + (c - J.seg[sg].c0) : o.dst;
+        o.ld = in ? J.seg[sg].ld : o.ld;
+        o.relu = in ? J.seg[sg].relu : o.relu;
+    }
+    if (c >= J.n_out) o.dst = nullptr;
+    return o;
+}
+
+// Accumulator rows of a lane: (reg & 3) + 8 * (reg >> 2) + 4 * h.  All 16 stores are issued back to back: nothing in
+// here may wait on memory (a wait between two stores serialises them on the store acknowledgements, which is what
+// bounded the first version of this epilogue).  orow: row ids of a row-list job, loaded once per tile (-1 = past the
+// end); null-list jobs address arithmetically.
+__device__ __forceinline__ void store_tile(const f32x16 &acc, const OutCol o, float bias, bool listed, const int (&orow)[16],
+                                           unsigned valid, int64_t row0, int h) {
+    if (!o.dst) return;
+    float v[16];  // every value first, in straight-line code: the predicated stores below then touch no loaded register
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const float t = acc[reg] + bias;
+        v[reg] = o.relu ? fmaxf(t, 0.f) : t;
+    }
+    if (listed) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            if ((valid >> reg) & 1u) o.dst[(int64_t)orow[reg] * o.ld] = v[reg];
+        return;
+    }
+    float *p = o.dst + (row0 + 4 * h) * o.ld;
+    if (valid == 0xffffu) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) p[(int64_t)((reg & 3) + 8 * (reg >> 2)) * o.ld] = v[reg];
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            if ((valid >> reg) & 1u) p[(int64_t)((reg & 3) + 8 * (reg >> 2)) * o.ld] = v[reg];
+    }
+}
+
+// Row ids of the lane's 16 accumulator rows (row-list jobs) and the bit mask of those inside the job; consuming the
+// loads here keeps memory waits out of the epilogue.
+__device__ __forceinline__ unsigned load_orow(const int *rows, int64_t row0, int h, int64_t n_rows, int (&orow)[16]) {
+    unsigned valid = 0;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t g = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        orow[reg] = (rows && g < n_rows) ? rows[g] : 0;
+        valid |= (g < n_rows ? 1u : 0u) << reg;
+    }
+    if (rows) {
+        int probe = 0;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) probe |= orow[reg];
+        if (probe < 0) valid = 0;  // never true (ids are non-negative): makes the loads complete here
+    }
+    return valid;
+}
+
 // 4 waves = 4 row tiles per block share each 32-column B tile through a double-buffered LDS image
 // (one barrier per stage; the next tile's global loads are in flight during the MFMAs).
 template <int KH>
@@ -86,6 +153,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmBatch Bt, cons
     const int n_stage = nkc * nct;
     float a[KH];
     if (nkc == 1) load_a<KH>(J, srow, rv, h * KH, a);
+    int orow[16];
+    const unsigned valid = load_orow(rows, row0, h, n_rows, orow);
 
     float4 pre[NLD];
     auto fetch = [&](int stage) {
@@ -122,26 +191,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmBatch Bt, cons
         if (kci == nkc - 1) {
             // epilogue: this lane owns column c of rows (reg&3) + 8*(reg>>2) + 4*h
             const int c = col0 + r;
-            float *dst = nullptr;
-            int ld = 0, relu = 0;
-            for (int sg = 0; sg < J.n_seg; ++sg)
-                if (c >= J.seg[sg].c0 && c < J.seg[sg].c1) {
-                    dst = J.seg[sg].dst + (c - J.seg[sg].c0);
-                    ld = J.seg[sg].ld;
-                    relu = J.seg[sg].relu;
-                }
-            if (dst) {
-                const float bias = J.bias ? J.bias[c] : 0.f;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int64_t g = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    if (g >= n_rows) continue;
-                    const int64_t orow = rows ? (int64_t)rows[g] : g;
-                    float v = acc[reg] + bias;
-                    if (relu) v = fmaxf(v, 0.f);
-                    dst[orow * ld] = v;
-                }
-            }
+            const OutCol o = find_out(J, c);
+            const float bias = (J.bias && c < J.n_out) ? J.bias[c] : 0.f;
+            store_tile(acc, o, bias, rows != nullptr, orow, valid, row0, h);
         }
         if (s + 1 < n_stage) stash((s + 1) & 1);
     }
@@ -179,28 +231,31 @@ __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(cons
     }
     __syncthreads();
     const int stride = gridDim.x * NW;
-    const int *launch_rows = rows;
-    const int64_t launch_n_rows = n_rows;
-    for (int item = blockIdx.x * NW + (tid >> 6); item < Pa.n_items; item += stride) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // item, job and tile are wave-uniform: scalar loads
+    for (int item = blockIdx.x * NW + wave; item < Pa.n_items; item += stride) {
         int j = 0;
         while (j + 1 < Bt.n && item >= Pa.item_start[j + 1]) ++j;
         const GemmJob &J = Bt.j[j];
-        const int *rows = J.rows ? J.rows : launch_rows;
-        const int64_t n_rows = J.rows ? J.n_rows : launch_n_rows;
+        const int *jrows = J.rows ? J.rows : rows;
+        const int64_t jn = J.rows ? J.n_rows : n_rows;
         const int local = item - Pa.item_start[j];
         const int n_tiles = Pa.n_tiles[j];
         const int tile = local % n_tiles, grp = local / n_tiles;  // consecutive waves -> consecutive row tiles
         const int64_t row0 = (int64_t)tile * 32, grow = row0 + r;
-        const bool rv = grow < n_rows;
-        const int64_t srow = rv ? (rows ? (int64_t)rows[grow] : grow) : 0;
+        const bool rv = grow < jn;
+        const int64_t srow = rv ? (jrows ? (int64_t)jrows[grow] : grow) : 0;
         float a[KH];
         load_a<KH>(J, srow, rv, h * KH, a);
+        int orow[16];
+        const unsigned valid = load_orow(jrows, row0, h, jn, orow);
         const int ld = Pa.lds_ld[j];
         const float *bimg = g_lds + Pa.lds_off[j] + (h * KH) * ld + r;
         const int nct = (J.n_out + 31) / 32;
         const int ct_end = min(nct, (grp + 1) * kColGroup);
         for (int ct = grp * kColGroup; ct < ct_end; ++ct) {
             const int col0 = ct * 32, c = col0 + r;
+            const OutCol o = find_out(J, c);
+            const float bias = (J.bias && c < J.n_out) ? J.bias[c] : 0.f;  // in flight during the MFMAs
             float b[KH];
 #pragma unroll
             for (int kk = 0; kk < KH; ++kk) b[kk] = bimg[kk * ld + col0];
@@ -209,26 +264,7 @@ __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(cons
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
-            if (c >= J.n_out) continue;
-            float *dst = nullptr;
-            int ldo = 0, relu = 0;
-            for (int sg = 0; sg < J.n_seg; ++sg)
-                if (c >= J.seg[sg].c0 && c < J.seg[sg].c1) {
-                    dst = J.seg[sg].dst + (c - J.seg[sg].c0);
-                    ldo = J.seg[sg].ld;
-                    relu = J.seg[sg].relu;
-                }
-            if (!dst) continue;
-            const float bias = J.bias ? J.bias[c] : 0.f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t g = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (g >= n_rows) continue;
-                const int64_t orow = rows ? (int64_t)rows[g] : g;
-                float v = acc[reg] + bias;
-                if (relu) v = fmaxf(v, 0.f);
-                dst[orow * ldo] = v;
-            }
+            store_tile(acc, o, bias, jrows != nullptr, orow, valid, row0, h);
         }
     }
 }
