@@ -6,11 +6,20 @@
 // k-major blocks  B[k][col]  so one GEMM job can serve several channels that share the same input
 // (all P first-layer channels read the same x, models/base.py:192-193).
 //
-// f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain): one wave owns a 32-row
-// tile, keeps its A fragment in registers (lane (r, h) holds A[row r][k in h*KH .. h*KH+KH) -- the k order is
-// permuted identically on the B side, which a sum over k does not care about) and walks the job's 32-column tiles,
-// streaming the k-major B columns from L2.  No LDS, no barriers; 4 independent waves per block.
+// f32-input MFMA (exact fp32 products, fp32 accumulation).  Three kernels:
+//   gemm_persist_kernel  (k <= 128): persistent workgroups keep the whole k-major B (+ bias row) in LDS; one wave owns a
+//                        32-row tile, its A fragment in registers (lane (r, h) holds float4 chunks 2q + h of row r -- the k
+//                        order is permuted identically on the B side, which a sum over k does not care about), and walks
+//                        32-column tiles: 16 LDS reads ahead, 32 v_mfma_f32_32x32x2_f32, 16 stores with no memory wait
+//                        anywhere in the column loop.
+//   gemm_skinny_kernel   (<= 16 output columns): 64 rows per wave, 4 independent v_mfma_f32_16x16x4_f32 chains, float4 stores.
+//   gemm_mfma_kernel     (k > 128): B tiles staged through a double-buffered LDS image.
+// Measured (profiles/tools/gemm_bench.cpp, mfma_peak.cpp, mfma_lds.cpp): the fp32 matrix pipe sustains 154 TFLOP/s on this
+// part; the [N,64]x[64,576] first-layer transform runs at 66-75 TFLOP/s because its 630 MB of output stores and the MFMA
+// chains do not overlap better than that (stores alone: 0.13-0.19 ms, MFMAs alone: 0.17 ms, together 0.25-0.30 ms;
+// rocBLAS: 0.35 ms).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -29,8 +38,10 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 
 // Branch-free A fragment load: every lane issues all its float4 loads back to back (invalid rows / k-ranges are
 // clamped to a valid address and zeroed afterwards), then the edge-less-row transform is applied with selects.
-template <int KH>
+template <int KH, bool IL = false>
 __device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, int kbase, float (&a)[KH]) {
+    // IL: the two k-halves of a row interleave by float4 (kbase = 4h): one load instruction then reads 32 contiguous
+    // bytes per row instead of two 16-byte pieces 128 bytes apart
     const int K = J.K1 + J.K2;
     const bool alt = J.a1_mask != nullptr && rv && J.a1_mask[srow] != 0;
     float sc = 1.f;
@@ -43,7 +54,7 @@ __device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, 
     float4 v[KH / 4], bv[KH / 4];
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
-        const int k = kbase + q * 4;
+        const int k = IL ? kbase + q * 8 : kbase + q * 4;
         const bool ok = k < K;
         const float *p = (k < J.K1 || !ok) ? p1 + (ok ? k : 0) : p2 + (k - J.K1);
         v[q] = ld4(p);
@@ -51,7 +62,7 @@ __device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, 
     }
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
-        const int k = kbase + q * 4;
+        const int k = IL ? kbase + q * 8 : kbase + q * 4;
         float4 t = v[q];
         if (alt && k < J.K1) {  // same roundings as the aggregation kernel's finish_row: product, + bias, relu
             t = make_float4(fmaxf(sc * t.x + bv[q].x, 0.f), fmaxf(sc * t.y + bv[q].y, 0.f), fmaxf(sc * t.z + bv[q].z, 0.f),
@@ -120,7 +131,7 @@ __device__ __forceinline__ unsigned load_orow(const int *rows, int64_t row0, int
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int64_t g = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        orow[reg] = (rows && g < n_rows) ? rows[g] : 0;
+        orow[reg] = g < n_rows ? (rows ? rows[g] : (int)g) : 0;
         valid |= (g < n_rows ? 1u : 0u) << reg;
     }
     if (rows) {
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmBatch Bt, cons
 constexpr int kColGroup = 5;       // 32-column tiles per item
 struct PersistArgs {
     int n_items;                   // all jobs
+    int col_group;                 // 32-column tiles per item
     int item_start[kMaxBatch + 1]; // first item of job j
     int lds_off[kMaxBatch];        // float offset of job j's B image, row stride lds_ld[j]
     int lds_ld[kMaxBatch];
@@ -214,59 +226,323 @@ struct PersistArgs {
 
 extern __shared__ float g_lds[];
 
-template <int KH>
+template <int KH, bool LISTED>
 __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(const GemmBatch Bt, const PersistArgs Pa, const int *__restrict__ rows,
                                                             int64_t n_rows) {
     constexpr int NT = KH > 32 ? 512 : 1024, NW = NT / 64;  // deeper k needs more registers per lane
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    // B images, 8 float4 loads in flight per thread
     for (int j = 0; j < Bt.n; ++j) {
         const GemmJob &J = Bt.j[j];
-        const int K = J.K1 + J.K2, ld = Pa.lds_ld[j], q4 = ld / 4;
-        float *dst = g_lds + Pa.lds_off[j];
-        for (int idx = tid; idx < 2 * KH * q4; idx += NT) {
-            const int k = idx / q4, c = (idx % q4) * 4;
-            const float4 v = (k < K && c < J.ldb) ? ld4(J.B + (size_t)k * J.ldb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(dst + k * ld + c) = v;
+        const int K = J.K1 + J.K2, ld = Pa.lds_ld[j], q4 = ld / 4, total = 2 * KH * q4;
+        const float inv_q4 = 1.0f / (float)q4;
+        float4 *dst = reinterpret_cast<float4 *>(g_lds + Pa.lds_off[j]);
+        constexpr int U = 8;
+        for (int base = 0; base < total; base += NT * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * NT + tid;
+                const int k = (int)(((float)idx + 0.5f) * inv_q4), c = (idx - k * q4) * 4;
+                v[u] = (idx < total && k < K && c < J.ldb) ? ld4(J.B + (size_t)k * J.ldb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * NT + tid;
+                if (idx < total) dst[idx] = v[u];
+            }
         }
+        // row 2*KH of the image: the bias, so the column loop below issues no global load at all (a load there
+        // makes every tile wait for the previous tile's stores to be acknowledged)
+        for (int c = tid; c < ld; c += NT) g_lds[Pa.lds_off[j] + 2 * KH * ld + c] = (J.bias && c < J.n_out) ? J.bias[c] : 0.f;
     }
     __syncthreads();
     const int stride = gridDim.x * NW;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // item, job and tile are wave-uniform: scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // item, job and tile are wave-uniform: scalar registers
     for (int item = blockIdx.x * NW + wave; item < Pa.n_items; item += stride) {
         int j = 0;
         while (j + 1 < Bt.n && item >= Pa.item_start[j + 1]) ++j;
         const GemmJob &J = Bt.j[j];
-        const int *jrows = J.rows ? J.rows : rows;
-        const int64_t jn = J.rows ? J.n_rows : n_rows;
+        const int *jrows = LISTED ? (J.rows ? J.rows : rows) : nullptr;
+        const int64_t jn = (LISTED && J.rows) ? J.n_rows : n_rows;
         const int local = item - Pa.item_start[j];
         const int n_tiles = Pa.n_tiles[j];
         const int tile = local % n_tiles, grp = local / n_tiles;  // consecutive waves -> consecutive row tiles
         const int64_t row0 = (int64_t)tile * 32, grow = row0 + r;
         const bool rv = grow < jn;
-        const int64_t srow = rv ? (jrows ? (int64_t)jrows[grow] : grow) : 0;
-        float a[KH];
-        load_a<KH>(J, srow, rv, h * KH, a);
-        int orow[16];
-        const unsigned valid = load_orow(jrows, row0, h, jn, orow);
-        const int ld = Pa.lds_ld[j];
-        const float *bimg = g_lds + Pa.lds_off[j] + (h * KH) * ld + r;
-        const int nct = (J.n_out + 31) / 32;
-        const int ct_end = min(nct, (grp + 1) * kColGroup);
-        for (int ct = grp * kColGroup; ct < ct_end; ++ct) {
-            const int col0 = ct * 32, c = col0 + r;
-            const OutCol o = find_out(J, c);
-            const float bias = (J.bias && c < J.n_out) ? J.bias[c] : 0.f;  // in flight during the MFMAs
-            float b[KH];
+        const int64_t srow = rv ? ((LISTED && jrows) ? (int64_t)jrows[grow] : grow) : 0;
+        // everything the column loop needs from the job, read once per item (scalar registers): the loop itself
+        // then has no scalar-memory wait, which shares its counter with the LDS reads
+        const int n_out = J.n_out, n_seg = J.n_seg;
+        GemmSegment S[kMaxSegments];
 #pragma unroll
-            for (int kk = 0; kk < KH; ++kk) b[kk] = bimg[kk * ld + col0];
+        for (int sg = 0; sg < kMaxSegments; ++sg) {
+            S[sg] = J.seg[sg < n_seg ? sg : 0];
+            if (sg >= n_seg) S[sg].c1 = S[sg].c0;
+        }
+        float a[KH];
+        load_a<KH, true>(J, srow, rv, 4 * h, a);
+        int orow[16];
+        unsigned valid = 0xffffu;
+        if (LISTED || row0 + 32 > jn) valid = load_orow(jrows, row0, h, jn, orow);
+        const int ld = Pa.lds_ld[j];
+        // k order of a lane: float4 chunks 2q + h of the row (the two halves of a row interleave by 16 bytes, so one
+        // load instruction reads 32 contiguous bytes per row); the B image is read with the same permutation
+        const float *bimg = g_lds + Pa.lds_off[j] + (4 * h) * ld + r;
+        const float *bias_img = g_lds + Pa.lds_off[j] + 2 * KH * ld + r;
+        const int nct = (n_out + 31) / 32;
+        const int ct_end = min(nct, (grp + 1) * Pa.col_group);
+        for (int ct = grp * Pa.col_group; ct < ct_end; ++ct) {
+            const int col0 = ct * 32, c = col0 + r;
+            const float bias = bias_img[col0];
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            // B fragment in batches of 8 LDS reads, the next batch issued before this batch's MFMAs
+            float bb[2][8];
 #pragma unroll
-            for (int kk = 0; kk < KH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
-            store_tile(acc, o, bias, jrows != nullptr, orow, valid, row0, h);
+            for (int u = 0; u < 8; ++u) bb[0][u] = bimg[(8 * (u / 4) + u % 4) * ld + col0];
+#pragma unroll
+            for (int g = 0; g < KH / 8; ++g) {
+                if (g + 1 < KH / 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) bb[(g + 1) & 1][u] = bimg[(16 * (g + 1) + 8 * (u / 4) + u % 4) * ld + col0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * g + u], bb[g & 1][u], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // epilogue: lane (r, h) owns column c of rows (reg & 3) + 8 * (reg >> 2) + 4h.  Nothing in here waits on
+            // memory, so the 16 stores go out back to back.
+            float *dst = nullptr;
+            int ldo = 0, relu = 0;
+#pragma unroll
+            for (int sg = 0; sg < kMaxSegments; ++sg) {
+                const bool in = c >= S[sg].c0 && c < S[sg].c1;
+                dst = in ? S[sg].dst + (c - S[sg].c0) : dst;
+                ldo = in ? S[sg].ld : ldo;
+                relu = in ? S[sg].relu : relu;
+            }
+            if (c >= n_out || !dst) continue;
+            float v[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float t = acc[reg] + bias;
+                v[reg] = relu ? fmaxf(t, 0.f) : t;
+            }
+            if (LISTED) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    if ((valid >> reg) & 1u) dst[(int64_t)orow[reg] * ldo] = v[reg];
+            } else {
+                float *p = dst + (row0 + 4 * h) * ldo;
+                if (valid == 0xffffu) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) p[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldo] = v[reg];
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if ((valid >> reg) & 1u) p[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldo] = v[reg];
+                }
+            }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- narrow outputs
+// Transforms with at most 16 output columns (the last layer of every PEA channel: hidden -> repr_dim = 16) are bound
+// by how fast the [rows, K] input streams in, not by the matrix pipe, and a 32x32 tile would waste half of it.  One
+// wave owns 64 rows: 4 independent v_mfma_f32_16x16x4_f32 chains (one per 16-row group) with the WEIGHTS as the row
+// operand, so lane (j = lane % 16, q = lane / 16) ends up with row j's columns 4q..4q+3 -- one float4 store -- and its
+// 16 float4 input loads (all four groups) are issued before anything waits on them: twice the bytes in flight per
+// wave of the 32-row kernel.  k order per lane: float4 chunks 4i + q of the row (the four lanes of a row read 64
+// contiguous bytes per instruction); the weight image in LDS is read with the same permutation.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SkinnyArgs {
+    int n_items;
+    int item_start[kMaxBatch + 1];  // first item (64-row tile) of job j
+    int lds_off[kMaxBatch];         // float offset of job j's image: [KQ*16][16] weights + [16] bias
+};
+
+template <int KQ, bool LISTED>  // KQ float4 chunks per lane and 16-row group: K <= 16 * KQ
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmBatch Bt, const SkinnyArgs Sa, const int *__restrict__ rows,
+                                                          int64_t n_rows) {
+    constexpr int KP = 16 * KQ, G = 4;
+    const int tid = threadIdx.x, lane = tid & 63, jr = lane & 15, q = lane >> 4;
+    for (int j = 0; j < Bt.n; ++j) {
+        const GemmJob &J = Bt.j[j];
+        const int K = J.K1 + J.K2;
+        float *img = g_lds + Sa.lds_off[j];
+        for (int idx = tid; idx < KP * 16; idx += 512) {
+            const int k = idx >> 4, c = idx & 15;
+            img[idx] = (k < K && c < J.n_out) ? J.B[(size_t)k * J.ldb + c] : 0.f;
+        }
+        if (tid < 16) img[KP * 16 + tid] = (J.bias && tid < J.n_out) ? J.bias[tid] : 0.f;
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int stride = gridDim.x * 8;
+    for (int item = blockIdx.x * 8 + wave; item < Sa.n_items; item += stride) {
+        int j = 0;
+        while (j + 1 < Bt.n && item >= Sa.item_start[j + 1]) ++j;
+        const GemmJob &J = Bt.j[j];
+        const int *jrows = LISTED ? (J.rows ? J.rows : rows) : nullptr;
+        const int64_t jn = (LISTED && J.rows) ? J.n_rows : n_rows;
+        const int64_t row0 = (int64_t)(item - Sa.item_start[j]) * (16 * G);
+        const int K = J.K1 + J.K2, K1 = J.K1, n_out = J.n_out, n_seg = J.n_seg;
+        GemmSegment S[kMaxSegments];
+#pragma unroll
+        for (int sg = 0; sg < kMaxSegments; ++sg) {
+            S[sg] = J.seg[sg < n_seg ? sg : 0];
+            if (sg >= n_seg) S[sg].c1 = S[sg].c0;
+        }
+        // ---- input rows: all G * KQ float4 loads of the lane go out before the first use
+        int64_t srow[G];
+        bool rv[G], alt[G];
+        float sc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t grow = row0 + 16 * g + jr;
+            rv[g] = grow < jn;
+            srow[g] = rv[g] ? ((LISTED && jrows) ? (int64_t)jrows[grow] : grow) : 0;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            alt[g] = J.a1_mask != nullptr && rv[g] && J.a1_mask[srow[g]] != 0;
+            sc[g] = 1.f;
+            if (J.a1_scale) {
+                const float di = J.a1_scale[srow[g]];
+                sc[g] = alt[g] ? di * di : 1.f;
+            }
+        }
+        float4 xa[G][KQ];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float *p1 = alt[g] ? J.a1_alt + srow[g] * J.lda_alt : J.A1 + srow[g] * J.lda1;
+            const float *p2 = J.K2 > 0 ? J.A2 + srow[g] * J.lda2 : p1;
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const int k = 16 * i + 4 * q;
+                const bool ok = k < K;
+                const float *p = (k < K1 || !ok) ? p1 + (ok ? k : 0) : p2 + (k - K1);
+                xa[g][i] = ld4(p);
+            }
+        }
+        float4 ab[KQ];  // bias of the edge-less-row transform (same for every row)
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            const int k = 16 * i + 4 * q;
+            ab[i] = (J.a1_mask != nullptr && k < K1) ? ld4(J.a1_bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // ---- weights of this job: lane (col = jr, q) holds W[16i + 4q + e][jr]
+        const float *img = g_lds + Sa.lds_off[j];
+        float w[KQ][4];
+#pragma unroll
+        for (int i = 0; i < KQ; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[i][e] = img[(16 * i + 4 * q + e) * 16 + jr];
+        const float4 bias = *reinterpret_cast<const float4 *>(img + KP * 16 + 4 * q);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const int k = 16 * i + 4 * q;
+                float4 t = xa[g][i];
+                if (alt[g] && k < K1) {  // same roundings as the aggregation kernel's finish_row: product, + bias, relu
+                    t = make_float4(fmaxf(sc[g] * t.x + ab[i].x, 0.f), fmaxf(sc[g] * t.y + ab[i].y, 0.f),
+                                    fmaxf(sc[g] * t.z + ab[i].z, 0.f), fmaxf(sc[g] * t.w + ab[i].w, 0.f));
+                }
+                const bool keep = rv[g] && k < K;
+                xa[g][i] = keep ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        f32x4 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][0], xa[g][i].x, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][1], xa[g][i].y, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][2], xa[g][i].z, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][3], xa[g][i].w, acc[g], 0, 0, 0);
+        }
+        // ---- epilogue: columns c .. c+3 of row srow[g]
+        const int c = 4 * q;
+        float *dst = nullptr;
+        int ldo = 0, relu = 0;
+#pragma unroll
+        for (int sg = 0; sg < kMaxSegments; ++sg) {
+            const bool in = c >= S[sg].c0 && c < S[sg].c1;
+            dst = in ? S[sg].dst + (c - S[sg].c0) : dst;
+            ldo = in ? S[sg].ld : ldo;
+            relu = in ? S[sg].relu : relu;
+        }
+        if (c >= n_out || !dst) continue;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float4 v = make_float4(acc[g][0] + bias.x, acc[g][1] + bias.y, acc[g][2] + bias.z, acc[g][3] + bias.w);
+            if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (rv[g]) *reinterpret_cast<float4 *>(dst + srow[g] * ldo) = v;
+        }
+    }
+}
+
+// a job qualifies when its output is at most 16 columns wide, k fits 128 and every segment can take float4 stores
+static bool skinny_ok(const GemmJob &J) {
+    if (J.n_out > 16 || J.K1 + J.K2 > 128 || J.ldb < J.n_out) return false;
+    for (int sg = 0; sg < J.n_seg; ++sg) {
+        const GemmSegment &S = J.seg[sg];
+        if (S.c0 % 4 || S.c1 % 4 || S.ld % 4 || (reinterpret_cast<uintptr_t>(S.dst) & 15)) return false;
+    }
+    return true;
+}
+
+template <int KQ, bool LISTED>
+static int launch_skinny_v(const GemmBatch &Bt, const SkinnyArgs &Sa, size_t lds, int grid, const int *rows, int64_t n_rows,
+                           double bytes, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_skinny_kernel<KQ, LISTED>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set = true;
+    }
+    ProfScope ps("gemm_mfma_narrow", stream, bytes);
+    hipLaunchKernelGGL((gemm_skinny_kernel<KQ, LISTED>), dim3((unsigned)grid), dim3(512), lds, stream, Bt, Sa, rows, n_rows);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+template <int KQ>
+static int launch_skinny(const GemmBatch &Bt, const int *rows, int64_t n_rows, double bytes, hipStream_t stream) {
+    SkinnyArgs Sa;
+    int off = 0, items = 0;
+    bool listed = rows != nullptr;
+    for (int j = 0; j < Bt.n; ++j) {
+        listed = listed || Bt.j[j].rows != nullptr;
+        Sa.lds_off[j] = off;
+        off += (16 * KQ + 1) * 16;
+        Sa.item_start[j] = items;
+        items += (int)(((Bt.j[j].rows ? Bt.j[j].n_rows : n_rows) + 63) / 64);
+    }
+    Sa.item_start[Bt.n] = items;
+    Sa.n_items = items;
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        PEA_HIP(hipGetDevice(&dev));
+        PEA_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+    }
+    const int grid = std::min(n_cu * 2, (items + 7) / 8);
+    const size_t lds = (size_t)off * sizeof(float);
+    return listed ? launch_skinny_v<KQ, true>(Bt, Sa, lds, grid, rows, n_rows, bytes, stream)
+                  : launch_skinny_v<KQ, false>(Bt, Sa, lds, grid, rows, n_rows, bytes, stream);
 }
 
 struct PackLaunch {
@@ -324,17 +600,36 @@ static int check_job(const GemmJob &job) {
 
 constexpr size_t kLdsBudget = 160 * 1024 - 1024;  // dynamic LDS a workgroup may claim (one workgroup per CU)
 
+template <int KH, bool LISTED>
+int launch_persist_v(const GemmBatch &Bt, const PersistArgs &Pa, size_t lds, int grid, const int *rows, int64_t n_rows,
+                     double bytes, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_persist_kernel<KH, LISTED>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    constexpr int NT = KH > 32 ? 512 : 1024;
+    ProfScope ps(Bt.n == 1 ? "gemm_mfma_shared" : "gemm_mfma_batch", stream, bytes);
+    hipLaunchKernelGGL((gemm_persist_kernel<KH, LISTED>), dim3((unsigned)grid), dim3(NT), lds, stream, Bt, Pa, rows, n_rows);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
 template <int KH>
 int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double bytes, hipStream_t stream) {
     PersistArgs Pa;
+    Pa.col_group = kColGroup;
     int off = 0, items = 0;
+    bool listed = rows != nullptr;
     for (int j = 0; j < Bt.n; ++j) {
         const int nct = (Bt.j[j].n_out + 31) / 32;
         const int n_tiles = (int)(((Bt.j[j].rows ? Bt.j[j].n_rows : n_rows) + 31) / 32);
+        listed = listed || Bt.j[j].rows != nullptr;
         Pa.n_tiles[j] = n_tiles;
         Pa.lds_ld[j] = nct * 32;
         Pa.lds_off[j] = off;
-        off += 2 * KH * Pa.lds_ld[j];
+        off += (2 * KH + 1) * Pa.lds_ld[j];
         Pa.item_start[j] = items;
         items += n_tiles * ((nct + kColGroup - 1) / kColGroup);
     }
@@ -349,19 +644,11 @@ int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double 
         PEA_HIP(hipGetDeviceProperties(&prop, dev));
         n_cu = prop.multiProcessorCount;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_persist_kernel<KH>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
-    }
     const int per_cu = lds * 2 <= kLdsBudget ? 2 : 1;  // two workgroups share a CU when their B images both fit
     constexpr int NT = KH > 32 ? 512 : 1024;
     const int grid = std::min(n_cu * per_cu, (items + NT / 64 - 1) / (NT / 64));
-    ProfScope ps(Bt.n == 1 ? "gemm_mfma_shared" : "gemm_mfma_batch", stream, bytes);
-    hipLaunchKernelGGL(gemm_persist_kernel<KH>, dim3((unsigned)grid), dim3(NT), lds, stream, Bt, Pa, rows, n_rows);
-    PEA_HIP(hipGetLastError());
-    return PEA_OK;
+    return listed ? launch_persist_v<KH, true>(Bt, Pa, lds, grid, rows, n_rows, bytes, stream)
+                  : launch_persist_v<KH, false>(Bt, Pa, lds, grid, rows, n_rows, bytes, stream);
 }
 
 // Jobs of one call share the row set; jobs with the same k-depth class go out as one launch.  A job whose B does
@@ -369,13 +656,41 @@ int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double 
 int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, int64_t n_rows, hipStream_t stream) {
     if (n_jobs_in <= 0) return PEA_OK;
     std::vector<GemmJob> jobs;
+    // narrow outputs first: one launch per k class
+    for (int kq : {2, 4, 8}) {
+        GemmBatch Bt;
+        Bt.n = 0;
+        double bytes = 0.0;
+        auto flush = [&]() -> int {
+            if (Bt.n == 0) return PEA_OK;
+            int rc = kq == 2 ? launch_skinny<2>(Bt, rows, n_rows, bytes, stream)
+                     : kq == 4 ? launch_skinny<4>(Bt, rows, n_rows, bytes, stream)
+                               : launch_skinny<8>(Bt, rows, n_rows, bytes, stream);
+            Bt.n = 0;
+            bytes = 0.0;
+            return rc;
+        };
+        for (int i = 0; i < n_jobs_in; ++i) {
+            const GemmJob &J = jobs_in[i];
+            const int K = J.K1 + J.K2;
+            if (!skinny_ok(J) || (K <= 32 ? 2 : K <= 64 ? 4 : 8) != kq) continue;
+            PEA_TRY(check_job(J));
+            const int64_t nr = J.rows ? J.n_rows : n_rows;
+            if (nr <= 0) continue;
+            Bt.j[Bt.n++] = J;
+            bytes += 4.0 * (double)nr * (K + J.n_out);
+            if (Bt.n == kMaxBatch) PEA_TRY(flush());
+        }
+        PEA_TRY(flush());
+    }
     for (int i = 0; i < n_jobs_in; ++i) {
+        if (skinny_ok(jobs_in[i])) continue;
         PEA_TRY(check_job(jobs_in[i]));
         const GemmJob &J = jobs_in[i];
         if ((J.rows ? J.n_rows : n_rows) <= 0) continue;
         const int K = J.K1 + J.K2;
         const int KH = K <= 32 ? 16 : K <= 64 ? 32 : 64;
-        const int max_cols = (int)(kLdsBudget / sizeof(float) / (size_t)(2 * KH)) / 32 * 32;
+        const int max_cols = (int)(kLdsBudget / sizeof(float) / (size_t)(2 * KH + 1)) / 32 * 32;
         if (K > 128 || J.n_out <= max_cols) {
             jobs.push_back(J);
             continue;
@@ -433,7 +748,7 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                 const int K = jobs[i].K1 + jobs[i].K2;
                 const int cls = K <= 32 ? 16 : K <= 64 ? 32 : 64;
                 if (cls != classes[ci] || (K > 128) != (deep == 1)) continue;
-                const size_t need = (size_t)2 * cls * ((jobs[i].n_out + 31) / 32 * 32) * sizeof(float);
+                const size_t need = (size_t)(2 * cls + 1) * ((jobs[i].n_out + 31) / 32 * 32) * sizeof(float);
                 if (!deep && Bt.n > 0 && lds + need > kLdsBudget) PEA_TRY(flush());
                 Bt.j[Bt.n++] = jobs[i];
                 lds += need;
