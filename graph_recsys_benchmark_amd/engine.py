@@ -192,9 +192,10 @@ class PEAEngine:
                     row.append((d, src, dst, plan.source_layouts[d.relation]))
                 self._exchanges.append(row)
 
-    def forward(self, layer_params, x, att=None, masked=None, want_stack=False, train=False):
+    def forward(self, layer_params, x, att=None, masked=None, want_stack=False, train=False, gather=True):
         """layer_params: list (channel-major, then step) of tuples of tensors in PARAM_SLOTS order
-        (a missing bias may be None).  train=True keeps what backward() needs (single GPU)."""
+        (a missing bias may be None).  train=True keeps what backward() needs (single GPU).  gather=False (sharded
+        plans only): skip the final all-gather; only the rows this rank owns are defined in the result."""
         lib = _lib.load()
         n = self.plan.num_nodes
         if x.shape != (n, self.emb_dim) or x.dtype != torch.float32 or not x.is_cuda:
@@ -245,9 +246,10 @@ class PEAEngine:
             if k + 1 < self.n_stages:
                 for d, src, dst, lay in self._exchanges[k + 1]:
                     shard.exchange_sources(dst, src, lay, d.src_col, d.width)
-        shard.allgather_rows(out)
-        if want_stack:
-            shard.allgather_rows(stack)
+        if gather:
+            shard.allgather_rows(out)
+            if want_stack:
+                shard.allgather_rows(stack)
         return (out, stack) if want_stack else out
 
     def __del__(self):

@@ -67,6 +67,7 @@ class GraphRecsysModel(torch.nn.Module):
         """nn.Module.eval() + refresh of the cached full-graph representation.  Like the reference
         (models/base.py:88-96) the ablation index is honoured only by classes whose NAME starts with 'PEA'."""
         super().eval()
+        self._repr_partial = False
         with torch.no_grad():
             if self.__class__.__name__[:3] == 'PEA':
                 self.cached_repr = self.forward(metapath_idx)
@@ -205,7 +206,41 @@ class PEABaseRecsysModel(GraphRecsysModel):
             out = torch.sum(x * atts, dim=1)
         return (out, stack) if return_stack else out
 
+    def loss(self, pos_neg_pair_t):
+        """Sharded training-mode loss without autograd: every rank computes the rows it owns, then only the rows the
+        batch names are exchanged (one all-reduce of [3B, repr_dim]) instead of all-gathering the [N, repr_dim] table;
+        same value as the single-GPU loss.  cached_repr is completed lazily if predict() is called before eval()."""
+        sharded = self._shard[1] > 1
+        if not (sharded and self.training) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return super().loss(pos_neg_pair_t)
+        eng = self._get_engine()
+        part = eng.forward(self._layer_params(), self.x.detach(), getattr(self, 'att', None), gather=False)
+        self.cached_repr, self._repr_partial = part, True
+        t = pos_neg_pair_t
+        b = t.shape[0]
+        rows = eng.plan.layout.gather_rows(part, t[:, :3].reshape(-1))
+        local = torch.arange(3 * b, dtype=torch.int64, device=t.device).view(b, 3)
+        cf_loss = _engine.bpr_score(rows, local, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        if self.entity_aware:
+            x = self.x.detach()
+
+            def sqdist(a, c):
+                d = x[t[:, a]] - x[t[:, c]]
+                return (d * d).sum(dim=-1)
+
+            item_term = (sqdist(1, 3) - sqdist(1, 4)) * t[:, 5]
+            user_term = (sqdist(0, 6) - sqdist(0, 7)) * t[:, 8]
+            reg = -item_term.sigmoid().log().sum() - user_term.sigmoid().log().sum()
+            return cf_loss + self.entity_aware_coff * reg
+        return cf_loss
+
+    def _complete_repr(self):
+        if getattr(self, '_repr_partial', False):
+            self._get_engine().plan.layout.allgather_rows(self.cached_repr)
+            self._repr_partial = False
+
     def predict(self, unids, inids):
+        self._complete_repr()
         if self.cached_repr.requires_grad:
             z = torch.cat([self.cached_repr[unids], self.cached_repr[inids]], dim=-1)
             return self.fc2(torch.relu(self.fc1(z)))

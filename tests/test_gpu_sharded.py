@@ -51,6 +51,22 @@ def _worker(rank, world, port, kind, heads):
             model.shard(0, 1)
             ref_masked = model.forward(metapath_idx=2)
         assert torch.equal(got, ref), 'rank %d: fused rows differ (max %g)' % (rank, (got - ref).abs().max())
+        # training-mode loss of a sharded model: batch rows only are exchanged; same value as the single-rank loss
+        rng = np.random.default_rng(4)
+        (u0, u1), (i0, i1) = blocks['u'], blocks['i']
+        batch = torch.from_numpy(np.stack([rng.integers(u0, u1, 256), rng.integers(i0, i1, 256),
+                                           rng.integers(i0, i1, 256)], axis=1).astype(np.int64)).cuda()
+        model.train()
+        with torch.no_grad():
+            ref_loss = model.loss(batch)
+            model.shard(rank, world, tile=64)
+            got_loss = model.loss(batch)
+            assert model._repr_partial
+            pred = model.predict(batch[:, 0], batch[:, 1])            # completes the cached table lazily
+            assert torch.equal(model.cached_repr, ref) and not model._repr_partial and pred.shape == (256, 1)
+            model.shard(0, 1)
+        model.eval()
+        assert torch.equal(got_loss, ref_loss), 'rank %d: loss %r vs %r' % (rank, got_loss, ref_loss)
         assert torch.equal(got_stack, ref_stack)
         assert torch.equal(masked, ref_masked)
         info = model._engine.plan.relation_info(0)

@@ -62,6 +62,10 @@ def _worker(rank, world, port, tile):
         shard.allgather_rows(table)
         torch.testing.assert_close(table, truth, rtol=0, atol=0)
 
+        # 3b. batch-row exchange: only the rows a batch names, summed from their owners (exact: x + 0)
+        ids = torch.tensor([0, n - 1, 5, 5, tile, tile - 1, 2 * tile + 3, 77], dtype=torch.int64)
+        torch.testing.assert_close(shard.gather_rows(local, ids), truth[ids], rtol=0, atol=0)   # `local` is NaN off-rank
+
         # 4. dependency check with the oracle: a rank that knows the conv input only on (owned rows + the
         #    relation's source nodes) still gets its owned output rows right (NaN-poisoned elsewhere)
         rng = np.random.default_rng(0)
