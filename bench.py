@@ -258,7 +258,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, want = cpu_baseline(dataset, model, args.kind)
         out['cpu_baseline'] = base
-        got = model.cached_repr.detach().cpu().numpy()       # full-size parity of the fused table against the oracle
+        with torch.no_grad():                                 # same weights as the oracle run (Adam may have stepped above)
+            got = model.forward().cpu().numpy()               # full-size parity of the fused table against the oracle
         out['parity_vs_cpu_oracle'] = {'max_abs_err': float(np.abs(got - want).max()),
                                        'max_abs_value': float(np.abs(want).max()), 'rows': int(want.shape[0])}
     if rank == 0:

@@ -39,6 +39,16 @@ class ExchangeDesc(C.Structure):
                 ('src_col', C.c_int)]
 
 
+class GwJob(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('lda', C.c_int64), ('ma', C.c_int), ('b', C.c_void_p), ('ldb', C.c_int64),
+                ('nb', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64)]
+
+
+class DenseJob(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('lda', C.c_int64), ('k', C.c_int), ('w', C.c_void_p), ('ldw', C.c_int64),
+                ('n_out', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64)]
+
+
 # every symbol include/peahip.h declares: name -> (restype, argtypes)
 _vp, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 SIGNATURES = {
@@ -70,6 +80,9 @@ SIGNATURES = {
     'pea_sage_conv': (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _int, _vp, _i64, _vp, _sz, _vp]),
     'pea_weighted_aggregate_workspace_bytes': (_sz, [_vp, _int, _int]),
     'pea_weighted_aggregate': (_int, [_vp, _int, _int, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp]),
+    'pea_grad_weight_workspace_bytes': (_sz, []),
+    'pea_grad_weight': (_int, [_i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
+    'pea_dense_batch': (_int, [_i64, _int, C.POINTER(DenseJob), _vp]),
     'pea_fuse': (_int, [_i64, _int, _int, _vp, _i64, C.POINTER(_int), _vp, _int, _int, _vp, _vp]),
     'pea_bpr_workspace_bytes': (_sz, [_i64]),
     'pea_bpr_score': (_int, [_i64, _int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import PARAM_SLOTS
+from .engine import PARAM_SLOTS, dense_batch, grad_weight
 
 
 class _Layout:
@@ -95,8 +95,7 @@ def backward_conv_stack(engine, d_stack, x, layer_params):
                 G = (dX if u['last'] else dO)[:, u['o_col']:u['o_col'] + u['HF']]
                 M = T[:, u['t_col']:u['t_col'] + u['in_w']]
                 In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
-                grads[li][0] = G.t() @ M
-                grads[li][2] = G.t() @ In
+                grads[li][0], grads[li][2] = grad_weight([(G, M), (G, In)])
                 grads[li][1] = gpack[u['bias_off']:u['bias_off'] + u['HF']].clone()
                 dT[:, u['t_col']:u['t_col'] + u['in_w']] += G @ w_rel          # level 0: channels of one relation share M
                 direct = G @ w_root
@@ -122,34 +121,39 @@ def backward_conv_stack(engine, d_stack, x, layer_params):
             ncol = units[-1]['t_col'] + units[-1]['HF']
             dT0 = dT[:, :ncol]
             if kind == 'gat':
-                dW_all = dT0.t() @ x                                        # [sum HF, emb]
+                dW_all = grad_weight([(dT0, x)])[0]                         # [sum HF, emb]
                 w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=0)
                 dx += dT0 @ w_cat
             else:
-                dW_all = x.t() @ dT0                                        # [emb, sum F]
+                dW_all = grad_weight([(x, dT0)])[0]                         # [emb, sum F]
                 w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=1)
                 dx += dT0 @ w_cat.t()
-        for u in units:
-            li = first[u['p']] + u['s']
-            dTu = dT[:, u['t_col']:u['t_col'] + u['HF']]
-            if kind == 'gat':
-                if s == 0:
-                    grads[li][0] = dW_all[u['t_col']:u['t_col'] + u['HF']]
+        # weight gradients of the level in one launch pair, input gradients in one launch (dense_bwd.hip)
+        if s > 0:
+            pairs, dense = [], []
+            for u in units:
+                li = first[u['p']] + u['s']
+                dTu = dT[:, u['t_col']:u['t_col'] + u['HF']]
+                In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
+                dIn = dIn_all[:, u['in_col']:u['in_col'] + u['in_w']]
+                if kind == 'gat':
+                    pairs.append((dTu, In))                                     # [HF, in]
+                    dense.append((dTu, layer_params[li][0], dIn))               # dT @ W
                 else:
-                    In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
-                    grads[li][0] = dTu.t() @ In
-                    dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = dTu @ layer_params[li][0]
+                    pairs.append((In, dTu))                                     # [in, F]
+                    dense.append((dTu, layer_params[li][0].t().contiguous(), dIn))
+            dWs = grad_weight(pairs)
+            dense_batch(dense)
+        for q, u in enumerate(units):
+            li = first[u['p']] + u['s']
+            if kind == 'gat':
+                grads[li][0] = dW_all[u['t_col']:u['t_col'] + u['HF']] if s == 0 else dWs[q]
                 shape = layer_params[li][1].shape
                 grads[li][1] = gpack[lv['att_dst_off'] + u['t_col']:lv['att_dst_off'] + u['t_col'] + u['HF']].clone().view(shape)
                 grads[li][2] = gpack[lv['att_src_off'] + u['t_col']:lv['att_src_off'] + u['t_col'] + u['HF']].clone().view(shape)
                 grads[li][3] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
             else:
-                if s == 0:
-                    grads[li][0] = dW_all[:, u['t_col']:u['t_col'] + u['HF']]
-                else:
-                    In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
-                    grads[li][0] = In.t() @ dTu
-                    dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = dTu @ layer_params[li][0].t()
+                grads[li][0] = dW_all[:, u['t_col']:u['t_col'] + u['HF']] if s == 0 else dWs[q]
                 grads[li][1] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
     return dx, grads
 

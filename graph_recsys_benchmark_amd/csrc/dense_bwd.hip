@@ -1,0 +1,216 @@
+// Dense half of the PEA backward for gfx950 (reference solvers.py:213-216 loss.backward()):
+//   pea_grad_weight   dW = A^T B over the node dimension (torch.nn.Linear / matmul weight gradients of every conv layer:
+//                     [HF, N] x [N, in]) -- a few thousand outputs, a reduction over 10^5..10^7 rows.  BLAS treats it as a
+//                     tall-k GEMM and is 10-25x off its memory bound on these shapes (rocBLAS: 0.52 ms per [16,N]x[N,64]
+//                     on 273,744 rows, 87 MB of input); here the rows are cut into parts, every workgroup streams its part
+//                     once through v_mfma_f32_16x16x4_f32 (the reduction index IS the MFMA k, so both operands are read
+//                     row-contiguous with no transpose), and the per-part tiles are summed in a fixed order (no atomics).
+//   pea_dense_batch   out = A W for a batch of independent jobs (the input gradients dIn = dT W of one level in one
+//                     launch), on the forward transform kernels (gemm.hip).
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace pea {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGwParts = 128;     // row parts per job (grid.x)
+constexpr int kGwMaxJobs = 16;    // 64x64 blocks per launch
+struct GwJob {
+    const float *a, *b;
+    int64_t lda, ldb;
+    int ma, nb;       // valid columns of this block (<= 16 * MT, <= 16 * NT)
+    float *out;       // block origin, row stride ldo
+    int64_t ldo;
+};
+struct GwBatch {
+    int n;
+    GwJob j[kGwMaxJobs];
+};
+
+// stage 1: partial[job][part][MT*NT tiles][256] = sum over the part's rows of a[n][i] * b[n][j]
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, int64_t n_rows, float *__restrict__ partial) {
+    __shared__ float red[3][MT * NT * 256];
+    const GwJob &J = Jb.j[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int64_t chunk = ((n_rows + kGwParts - 1) / kGwParts + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = min(n_rows, r0 + chunk);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool am[MT], bm[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) am[mt] = 16 * mt + i < J.ma;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bm[nt] = 16 * nt + i < J.nb;
+    constexpr int U = 4;  // row groups in flight per wave (each: 4 rows, one dword per operand tile and lane)
+    for (int64_t n0 = r0 + 4 * wave; n0 < r1; n0 += 16 * U) {
+        float av[U][MT], bv[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t n = n0 + 16 * u + kq;
+            const bool ok = n < r1;
+            const int64_t nc = ok ? n : r0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[u][mt] = (ok && am[mt]) ? J.a[nc * J.lda + 16 * mt + i] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = (ok && bm[nt]) ? J.b[nc * J.ldb + 16 * nt + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+    }
+    // waves 1..3 park their tiles in LDS, wave 0 adds them in wave order and writes the part's record
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[wave - 1][((mt * NT + nt) * 4 + v) * 64 + lane] = acc[mt][nt][v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *dst = partial + ((size_t)blockIdx.y * kGwParts + blockIdx.x) * (MT * NT * 256);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int e = ((mt * NT + nt) * 4 + v) * 64 + lane;
+                    dst[e] = ((acc[mt][nt][v] + red[0][e]) + red[1][e]) + red[2][e];
+                }
+    }
+}
+
+// stage 2: out = sum over parts, part order.  Element e of a record: tile (mt, nt), register v, lane l ->
+// row 16 mt + 4 (l / 16) + v, column 16 nt + l % 16.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gw_stage2(const GwBatch Jb, const float *__restrict__ partial) {
+    const GwJob &J = Jb.j[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= MT * NT * 256) return;
+    const float *src = partial + (size_t)blockIdx.y * kGwParts * (MT * NT * 256) + e;
+    float s = 0.f;
+    for (int p = 0; p < kGwParts; ++p) s += src[(size_t)p * (MT * NT * 256)];
+    const int lane = e & 63, v = (e >> 6) & 3, t = e >> 8, mt = t / NT, nt = t % NT;
+    const int row = 16 * mt + 4 * (lane >> 4) + v, col = 16 * nt + (lane & 15);
+    if (row < J.ma && col < J.nb) J.out[(int64_t)row * J.ldo + col] = s;
+}
+
+template <int MT, int NT>
+int launch_gw(const GwBatch &Jb, int64_t n_rows, float *partial, double bytes, hipStream_t stream) {
+    {
+        ProfScope ps("grad_weight", stream, bytes);
+        hipLaunchKernelGGL((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, n_rows, partial);
+        PEA_HIP(hipGetLastError());
+    }
+    ProfScope ps("grad_weight_sum", stream);
+    hipLaunchKernelGGL((gw_stage2<MT, NT>), dim3(MT * NT, (unsigned)Jb.n), dim3(256), 0, stream, Jb, partial);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+int tiles_of(int w) { return w <= 16 ? 1 : w <= 32 ? 2 : 4; }
+
+}  // namespace
+}  // namespace pea
+
+using namespace pea;
+
+extern "C" size_t pea_grad_weight_workspace_bytes(void) {
+    return (size_t)kGwMaxJobs * kGwParts * 16 * 256 * sizeof(float) + 256;
+}
+
+extern "C" int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    PEA_REQUIRE(n_rows >= 0 && n_jobs >= 0 && (jobs_host || n_jobs == 0), PEA_ERR_ARG, "grad_weight: bad arguments");
+    PEA_REQUIRE(workspace && workspace_bytes >= pea_grad_weight_workspace_bytes(), PEA_ERR_NOMEM, "grad_weight: workspace too small");
+    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+    // cut every job into <= 64 x 64 blocks, group the blocks by tile shape, one pair of launches per shape and batch
+    std::vector<GwJob> blocks[3][3];
+    for (int q = 0; q < n_jobs; ++q) {
+        const pea_gw_job &S = jobs_host[q];
+        PEA_REQUIRE(S.a && S.b && S.out && S.ma > 0 && S.nb > 0 && S.lda >= S.ma && S.ldb >= S.nb && S.ldo >= S.nb,
+                    PEA_ERR_ARG, "grad_weight: job %d malformed", q);
+        for (int i0 = 0; i0 < S.ma; i0 += 64)
+            for (int j0 = 0; j0 < S.nb; j0 += 64) {
+                GwJob B;
+                B.a = S.a + i0;
+                B.b = S.b + j0;
+                B.lda = S.lda;
+                B.ldb = S.ldb;
+                B.ma = std::min(64, S.ma - i0);
+                B.nb = std::min(64, S.nb - j0);
+                B.out = S.out + (int64_t)i0 * S.ldo + j0;
+                B.ldo = S.ldo;
+                const int mt = tiles_of(B.ma), nt = tiles_of(B.nb);
+                blocks[mt == 1 ? 0 : mt == 2 ? 1 : 2][nt == 1 ? 0 : nt == 2 ? 1 : 2].push_back(B);
+            }
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const std::vector<GwJob> &L = blocks[a][b];
+            for (size_t base = 0; base < L.size(); base += kGwMaxJobs) {
+                GwBatch Jb;
+                Jb.n = (int)std::min<size_t>(kGwMaxJobs, L.size() - base);
+                double bytes = 0.0;
+                for (int q = 0; q < Jb.n; ++q) {
+                    Jb.j[q] = L[base + q];
+                    bytes += 4.0 * (double)n_rows * (Jb.j[q].ma + Jb.j[q].nb);
+                }
+                hipStream_t st = (hipStream_t)stream;
+                int rc = PEA_OK;
+                switch (a * 3 + b) {
+                    case 0: rc = launch_gw<1, 1>(Jb, n_rows, partial, bytes, st); break;
+                    case 1: rc = launch_gw<1, 2>(Jb, n_rows, partial, bytes, st); break;
+                    case 2: rc = launch_gw<1, 4>(Jb, n_rows, partial, bytes, st); break;
+                    case 3: rc = launch_gw<2, 1>(Jb, n_rows, partial, bytes, st); break;
+                    case 4: rc = launch_gw<2, 2>(Jb, n_rows, partial, bytes, st); break;
+                    case 5: rc = launch_gw<2, 4>(Jb, n_rows, partial, bytes, st); break;
+                    case 6: rc = launch_gw<4, 1>(Jb, n_rows, partial, bytes, st); break;
+                    case 7: rc = launch_gw<4, 2>(Jb, n_rows, partial, bytes, st); break;
+                    default: rc = launch_gw<4, 4>(Jb, n_rows, partial, bytes, st); break;
+                }
+                PEA_TRY(rc);
+            }
+        }
+    return PEA_OK;
+}
+
+extern "C" int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *jobs_host, void *stream) {
+    PEA_REQUIRE(n_rows >= 0 && n_jobs >= 0 && (jobs_host || n_jobs == 0), PEA_ERR_ARG, "dense_batch: bad arguments");
+    std::vector<GemmJob> jobs((size_t)n_jobs);
+    for (int q = 0; q < n_jobs; ++q) {
+        const pea_dense_job &S = jobs_host[q];
+        PEA_REQUIRE(S.a && S.w && S.out && S.k > 0 && S.n_out > 0 && S.k % 4 == 0 && S.n_out % 4 == 0 && S.lda % 4 == 0 &&
+                        S.ldw >= S.n_out && S.ldo >= S.n_out && S.lda >= S.k,
+                    PEA_ERR_ARG, "dense_batch: job %d malformed (widths and the input stride must be multiples of 4)", q);
+        GemmJob J{};
+        J.A1 = S.a;
+        J.lda1 = (int)S.lda;
+        J.K1 = S.k;
+        J.B = S.w;
+        J.ldb = (int)S.ldw;
+        J.n_out = S.n_out;
+        J.n_seg = 1;
+        J.seg[0].c0 = 0;
+        J.seg[0].c1 = S.n_out;
+        J.seg[0].dst = S.out;
+        J.seg[0].ld = (int)S.ldo;
+        J.seg[0].relu = 0;
+        jobs[(size_t)q] = J;
+    }
+    return launch_gemm_batch(jobs.data(), n_jobs, nullptr, n_rows, (hipStream_t)stream);
+}

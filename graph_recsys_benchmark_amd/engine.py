@@ -261,6 +261,60 @@ class PEAEngine:
                 pass
 
 
+def _rows2d(t):
+    if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+        raise ValueError('expected a CUDA float32 [rows, cols] view with unit column stride')
+    return t
+
+
+_gw_ws = {}
+
+
+def grad_weight(pairs):
+    """[a_q^T b_q for (a_q, b_q) in pairs]: a_q [N, ma], b_q [N, nb] float32 views (row strides free) over the same N
+    rows -- the weight gradients of one level in one pair of launches (pea_grad_weight: fixed-order reduction)."""
+    lib = _lib.require_device()
+    if not pairs:
+        return []
+    n = pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    jobs = (_lib.GwJob * len(pairs))()
+    outs = []
+    for q, (a, b) in enumerate(pairs):
+        a, b = _rows2d(a), _rows2d(b)
+        if a.shape[0] != n or b.shape[0] != n:
+            raise ValueError('grad_weight: operands of one call must share the row count')
+        out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=dev)
+        outs.append(out)
+        jobs[q] = _lib.GwJob(a.data_ptr(), a.stride(0), a.shape[1], b.data_ptr(), b.stride(0), b.shape[1],
+                             out.data_ptr(), out.stride(0))
+    ws = _gw_ws.get(dev)
+    if ws is None:
+        ws = _gw_ws[dev] = torch.empty(int(lib.pea_grad_weight_workspace_bytes()), dtype=torch.uint8, device=dev)
+    _lib.check(lib.pea_grad_weight(n, len(pairs), jobs, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    return outs
+
+
+def dense_batch(triples_):
+    """out_q = a_q @ w_q for (a_q [N, k], w_q [k, n_out], out_q [N, n_out] view) in triples_: one launch (the input
+    gradients dIn = dT W of one level); k, n_out and a's row stride must be multiples of 4."""
+    lib = _lib.require_device()
+    if not triples_:
+        return
+    n = triples_[0][0].shape[0]
+    jobs = (_lib.DenseJob * len(triples_))()
+    keep = []
+    for q, (a, w, out) in enumerate(triples_):
+        a, out = _rows2d(a), _rows2d(out)
+        w = _rows2d(w if w.stride(1) == 1 else w.contiguous())
+        keep.append(w)
+        if a.shape != (n, w.shape[0]) or out.shape != (n, w.shape[1]):
+            raise ValueError('dense_batch: shapes %s @ %s -> %s' % (tuple(a.shape), tuple(w.shape), tuple(out.shape)))
+        jobs[q] = _lib.DenseJob(a.data_ptr(), a.stride(0), w.shape[0], w.data_ptr(), w.stride(0), w.shape[1],
+                                out.data_ptr(), out.stride(0))
+    _lib.check(lib.pea_dense_batch(n, len(triples_), jobs, _lib.current_stream()))
+
+
 def bpr_score(repr_, triples, fc1_w, fc1_b, fc2_w, fc2_b, want_preds=False, validate=False):
     """loss = -sum(log(sigmoid(pos - neg))) over rows (u, i+, i-) of `triples` (reference models/base.py:46-48,
     208-214).  Returns a 0-dim tensor (and pos, neg [B] when asked)."""

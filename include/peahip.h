@@ -147,6 +147,28 @@ int pea_model_backward_level(pea_model *model, int level, int phase, void *works
                              void *stream);
 int pea_model_describe(const pea_model *model, int64_t *out_host, int max_len, int *needed_host);
 
+/* ---- dense half of the backward (the GEMMs the reference leaves to autograd: torch.nn.Linear / matmul inside the
+ * PyG convs, graph_recsys_benchmark/models/base.py:138-139 under loss.backward(), solvers.py:214) -------------------
+ * pea_grad_weight:  out[i][j] = sum_n a[n*lda + i] * b[n*ldb + j]   (i < ma, j < nb; out row stride ldo) for a batch of
+ *                   jobs over the same n_rows: the weight gradients dW = dT^T In (GAT lin, SAGE lin_rel / lin_root) or
+ *                   In^T dT (GCN).  Row parts are reduced in a fixed order: bitwise reproducible, no atomics.
+ * pea_dense_batch:  out[n][c] = sum_k a[n*lda + k] * w[k*ldw + c]   (k and n_out multiples of 4): the input gradients
+ *                   dIn = dT W of one level, all channels in one launch.                                              */
+typedef struct pea_gw_job {
+    const float *a; int64_t lda; int ma;
+    const float *b; int64_t ldb; int nb;
+    float *out; int64_t ldo;
+} pea_gw_job;
+typedef struct pea_dense_job {
+    const float *a; int64_t lda; int k;
+    const float *w; int64_t ldw; int n_out;
+    float *out; int64_t ldo;
+} pea_dense_job;
+size_t pea_grad_weight_workspace_bytes(void);
+int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes,
+                    void *stream);
+int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *jobs_host, void *stream);
+
 /* ---- multi-GPU (one process per GPU; the library itself never calls RCCL) -------------------------
  * A sharded plan (shard_world > 1) owns destination rows tile-interleaved.  The host mirror computes the layouts
  * with torch ops (graph_recsys_benchmark_amd/sharding.py) and hands them over:
