@@ -17,8 +17,8 @@ def short(name):
     if m:
         mode = {'0': 'gat', '1': 'gcn', '2': 'mean'}[m.group(3)]
         return '%s_g%s_%s' % (m.group(1).replace('_kernel', ''), m.group(2), mode)
-    m = re.search(r'(gemm_mfma|gemm_persist)_kernel<(\d+)>', name)
-    if m:
+    m = re.search(r'(gemm_mfma|gemm_persist|gemm_skinny)_kernel<(\d+)', name)
+    if m:                        # bench.py names: gemm_persist = gemm_mfma_shared / _batch, gemm_skinny = gemm_mfma_narrow
         return '%s_k%s' % (m.group(1), m.group(2))
     m = re.search(r'pea::\(anonymous namespace\)::(\w+)', name)
     return m.group(1) if m else name[:48]
