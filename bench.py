@@ -155,13 +155,22 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
-    # clock settle: the part ramps its clocks over the first few hundred ms of load, so keep stepping (untimed)
-    # until 0.3 s have passed; the timed region below then sees the steady state the steps after it would see
+    # clock settle: the part ramps its clocks over the first few hundred ms of load, so keep stepping (untimed) for
+    # about 0.3 s; the timed region below then sees the steady state the steps after it would see.  Every rank must
+    # run the SAME number of steps (each step holds collectives): the count comes from a max-reduced probe.
     torch.cuda.synchronize()
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.3:
+    t_probe = time.perf_counter()
+    for _ in range(3):
         loss = step()
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    per_step = torch.tensor([(time.perf_counter() - t_probe) / 3], dtype=torch.float64,
+                            device=device if (world > 1 and args.backend == 'nccl') else 'cpu')
+    if world > 1:
+        dist.all_reduce(per_step, op=dist.ReduceOp.MAX)
+    n_settle = int(min(2000, max(1, 0.3 / max(float(per_step.item()), 1e-6))))
+    for _ in range(n_settle):
+        loss = step()
+    torch.cuda.synchronize()
     lib = _lib.load()
     profile = not args.no_profile
 
