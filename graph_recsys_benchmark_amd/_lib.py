@@ -83,6 +83,7 @@ SIGNATURES = {
     'pea_grad_weight_workspace_bytes': (_sz, []),
     'pea_grad_weight': (_int, [_i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_dense_batch': (_int, [_i64, _int, C.POINTER(DenseJob), _vp]),
+    'pea_sample_negatives': (_int, [_i64, _int, _vp, _vp, _i64, _i64, _vp, _i64, C.c_uint64, C.c_uint32, _vp, _i64, _vp, _vp]),
     'pea_fuse': (_int, [_i64, _int, _int, _vp, _i64, C.POINTER(_int), _vp, _int, _int, _vp, _vp]),
     'pea_bpr_workspace_bytes': (_sz, [_i64]),
     'pea_bpr_score': (_int, [_i64, _int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -7,6 +7,10 @@ seeds (`random.seed / np.random.seed / torch.manual_seed`, reference solvers.py:
 
 They stay on the host on purpose: numpy's legacy RandomState stream and Python's `random` are version-frozen, a
 device-side Philox stream would not reproduce the reference's ids.
+
+    device_negative_sampling   the ADDITIONAL device-side sampler: same strategies and output
+                               layout, its own Philox4x32-10 stream (csrc/sampler.hip); never a replacement for the
+                               bit-exact path above.
 """
 import random as rd
 
@@ -49,3 +53,33 @@ def generate_candidates(dataset, u_nid, num_neg_candidates=99):
     pos_i_nids = dataset.test_pos_unid_inid_map[u_nid]
     neg_i_nids = list(np.random.choice(dataset.neg_unid_inid_map[u_nid], size=(num_neg_candidates,)))
     return pos_i_nids, neg_i_nids
+
+
+def device_negative_sampling(dataset, seed, epoch=0, device='cuda', shuffle=True):
+    """BPR triples sampled ON THE GPU: int64 [M * num_negative_samples, 3] CUDA tensor (u, i+, i-), optionally shuffled
+    with torch.randperm on the device.  'random': uniform items; 'unseen': uniform over the items the user has no
+    training interaction with (the pool the reference draws from, datasets/movielens.py:929-937).  `epoch` selects an
+    independent stream per call (the Philox counter's fourth word)."""
+    from .. import _lib
+    lib = _lib.require_device()
+    if dataset.cf_loss_type != 'BPR':
+        raise NotImplementedError('only the BPR branch is on the accelerated path')
+    pos = torch.as_tensor(dataset.edge_index_nps['user2item']).to(device=device, dtype=torch.int64)
+    pos_u, pos_i = pos[0].contiguous(), pos[1].contiguous()
+    k = int(dataset.num_negative_samples)
+    lo, n_items = int(dataset.type_accs['iid']), int(dataset.num_iids)
+    keys = None
+    if dataset.sampling_strategy == 'unseen':
+        keys = torch.unique(pos_u * n_items + (pos_i - lo))        # ascending
+    elif dataset.sampling_strategy != 'random':
+        raise NotImplementedError
+    out = torch.empty((pos_u.numel() * k, 3), dtype=torch.int64, device=device)
+    exhausted = torch.zeros(1, dtype=torch.int32, device=device)
+    _lib.check(lib.pea_sample_negatives(pos_u.numel(), k, _lib.ptr(pos_u), _lib.ptr(pos_i), lo, n_items, _lib.ptr(keys),
+                                        0 if keys is None else keys.numel(), int(seed) & (2 ** 64 - 1),
+                                        int(epoch) & 0xFFFFFFFF, _lib.ptr(out), out.stride(0), _lib.ptr(exhausted),
+                                        _lib.current_stream()))
+    if shuffle:
+        out = out[torch.randperm(out.shape[0], device=device)]
+    dataset.train_data, dataset.train_data_length = out, out.shape[0]
+    return out

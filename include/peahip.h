@@ -169,6 +169,18 @@ int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, voi
                     void *stream);
 int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *jobs_host, void *stream);
 
+/* ---- device-side BPR negative sampler (an addition next to the bit-exact host mirror of the reference's
+ * datasets/movielens.py:920-940 in graph_recsys_benchmark_amd/utils/sampling.py) -----------------------------------
+ * For every training positive p and j < k writes row p*k + j of out_triples = (pos_u[p], pos_i[p], i-):
+ *   seen_keys_sorted == NULL : i- uniform over [item_lo, item_lo + num_items)               ('random' strategy)
+ *   otherwise                : i- uniform over the items with no key  u * num_items + (i - item_lo)  in the ascending
+ *                              int64 table (the user's training positives), by rejection       ('unseen' strategy)
+ * Stream: Philox4x32-10, key = seed, counter = (row lo, row hi, attempt, offset); exhausted (device int) counts rows
+ * whose 64 attempts all hit seen items (their last draw is kept).  All pointers are device pointers.            */
+int pea_sample_negatives(int64_t n_pos, int k, const int64_t *pos_u, const int64_t *pos_i, int64_t item_lo,
+                         int64_t num_items, const int64_t *seen_keys_sorted, int64_t n_keys, uint64_t seed,
+                         uint32_t offset, int64_t *out_triples, int64_t ld_out, int *exhausted, void *stream);
+
 /* ---- multi-GPU (one process per GPU; the library itself never calls RCCL) -------------------------
  * A sharded plan (shard_world > 1) owns destination rows tile-interleaved.  The host mirror computes the layouts
  * with torch ops (graph_recsys_benchmark_amd/sharding.py) and hands them over:
