@@ -162,8 +162,13 @@ class PEAStackFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, x, n_slots, *flat):
         layer_params = [tuple(flat[i:i + n_slots]) for i in range(0, len(flat), n_slots)]
-        _, stack = engine.forward(layer_params, x, att=torch.zeros(engine.P, engine.repr_dim, device=x.device),
-                                  want_stack=True, train=True)
+        # the fused table of the same launch is a free by-product (not differentiated here: the caller fuses the rows
+        # it needs with torch ops on the stack); engine.fuse_att / fuse_masked, when set, select what it is fused with
+        att = getattr(engine, 'fuse_att', None)
+        if att is None:
+            att = torch.zeros(engine.P, engine.repr_dim, device=x.device)
+        engine.last_fused, stack = engine.forward(layer_params, x, att=att, masked=getattr(engine, 'fuse_masked', None),
+                                                  want_stack=True, train=True)
         ctx.engine, ctx.n_slots = engine, n_slots
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
         ctx.present = [t is not None for t in flat]

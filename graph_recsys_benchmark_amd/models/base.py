@@ -193,25 +193,54 @@ class PEABaseRecsysModel(GraphRecsysModel):
         """Differentiable forward: conv stack forward + backward in HIP, fusion (models/base.py:194-203) in torch ops."""
         eng = self._get_engine(train=True)
         flat = [t for lp in self._layer_params() for t in lp]
+        eng.fuse_att, eng.fuse_masked = None, None
         stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
-        x = stack
+        out = self._fuse_torch(stack, metapath_idx)
+        return (out, stack) if return_stack else out
+
+    def _fuse_torch(self, x, metapath_idx=None):
+        """Channel fusion (models/base.py:194-203) of [rows, P, R] in differentiable torch ops."""
         if metapath_idx is not None:
             keep = torch.ones(x.shape[1], dtype=x.dtype, device=x.device)
             keep[metapath_idx] = 0
             x = x * keep.view(1, -1, 1)
         if self.channel_aggr == 'mean':
-            out = x.mean(dim=1)
-        else:
-            atts = torch.softmax(torch.sum(x * self.att, dim=-1), dim=-1).unsqueeze(-1)
-            out = torch.sum(x * atts, dim=1)
-        return (out, stack) if return_stack else out
+            return x.mean(dim=1)
+        atts = torch.softmax(torch.sum(x * self.att, dim=-1), dim=-1).unsqueeze(-1)
+        return torch.sum(x * atts, dim=1)
+
+    def _loss_autograd(self, t):
+        """Differentiable training-step loss, single GPU.  The fusion and the scorer are row-local, so they are
+        differentiated on the BATCH's rows of the channel stack only ([3B, P, R] instead of [N, P, R]: the dense torch
+        fusion and its backward cost ~2 ms per step on the 25m-shaped graph); the conv stack below runs forward and
+        backward in HIP over the whole graph as before.  Same loss as fusing everything and indexing afterwards
+        (reference models/base.py:44-48).  cached_repr is the fused table of the same forward (HIP, detached)."""
+        eng = self._get_engine(train=True)
+        flat = [p for lp in self._layer_params() for p in lp]
+        eng.fuse_att = self.att.detach().reshape(eng.P, eng.repr_dim) if self.channel_aggr == 'att' else None
+        eng.fuse_masked = None
+        stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
+        self.cached_repr, self._repr_partial = eng.last_fused, False
+        b = t.shape[0]
+        rows = self._fuse_torch(stack[t[:, :3].reshape(-1)]).view(b, 3, -1)
+
+        def score(i):
+            return self.fc2(torch.relu(self.fc1(torch.cat([rows[:, 0], rows[:, i]], dim=-1))))
+
+        return -(score(1) - score(2)).sigmoid().log().sum()
 
     def loss(self, pos_neg_pair_t):
         """Sharded training-mode loss without autograd: every rank computes the rows it owns, then only the rows the
         batch names are exchanged (one all-reduce of [3B, repr_dim]) instead of all-gathering the [N, repr_dim] table;
         same value as the single-GPU loss.  cached_repr is completed lazily if predict() is called before eval()."""
         sharded = self._shard[1] > 1
-        if not (sharded and self.training) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.training and grad and not sharded and self.x.is_cuda:
+            cf_loss = self._loss_autograd(pos_neg_pair_t)
+            if self.entity_aware:
+                return cf_loss + self.entity_aware_coff * self._entity_reg(pos_neg_pair_t, self.x)
+            return cf_loss
+        if not (sharded and self.training) or grad:
             return super().loss(pos_neg_pair_t)
         eng = self._get_engine()
         part = eng.forward(self._layer_params(), self.x.detach(), getattr(self, 'att', None), gather=False)
@@ -222,17 +251,19 @@ class PEABaseRecsysModel(GraphRecsysModel):
         local = torch.arange(3 * b, dtype=torch.int64, device=t.device).view(b, 3)
         cf_loss = _engine.bpr_score(rows, local, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         if self.entity_aware:
-            x = self.x.detach()
-
-            def sqdist(a, c):
-                d = x[t[:, a]] - x[t[:, c]]
-                return (d * d).sum(dim=-1)
-
-            item_term = (sqdist(1, 3) - sqdist(1, 4)) * t[:, 5]
-            user_term = (sqdist(0, 6) - sqdist(0, 7)) * t[:, 8]
-            reg = -item_term.sigmoid().log().sum() - user_term.sigmoid().log().sum()
-            return cf_loss + self.entity_aware_coff * reg
+            return cf_loss + self.entity_aware_coff * self._entity_reg(t, self.x.detach())
         return cf_loss
+
+    @staticmethod
+    def _entity_reg(t, x):
+        """entity-aware regulariser (reference models/base.py:50-76): squared L2 distances between raw x rows"""
+        def sqdist(a, c):
+            d = x[t[:, a]] - x[t[:, c]]
+            return (d * d).sum(dim=-1)
+
+        item_term = (sqdist(1, 3) - sqdist(1, 4)) * t[:, 5]
+        user_term = (sqdist(0, 6) - sqdist(0, 7)) * t[:, 8]
+        return -item_term.sigmoid().log().sum() - user_term.sigmoid().log().sum()
 
     def _complete_repr(self):
         if getattr(self, '_repr_partial', False):

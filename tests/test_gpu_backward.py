@@ -76,6 +76,9 @@ def test_backward_matches_float64_autograd(kind, heads, aggr):
     model.zero_grad()
     loss = model.loss(torch.from_numpy(batch).cuda())
     loss.backward()
+    with torch.no_grad():                       # training-mode loss() leaves the fused table of the same forward behind
+        assert not model.cached_repr.requires_grad
+        torch.testing.assert_close(model.cached_repr, model.forward(), rtol=1e-5, atol=1e-7)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     want_loss, want = f64_loss_and_grads(kind, sd, edges, steps, heads, aggr, batch)
     np.testing.assert_allclose(float(loss), want_loss, rtol=2e-5)
