@@ -72,6 +72,7 @@ SIGNATURES = {
     'pea_model_exchange_desc': (_int, [_vp, _int, _int, C.POINTER(ExchangeDesc)]),
     'pea_model_forward_train': (_int, [_vp, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
     'pea_model_backward_level': (_int, [_vp, _int, _int, _vp, _sz, _vp]),
+    'pea_model_set_active_rows': (_int, [_vp, _vp]),
     'pea_model_describe': (_int, [_vp, C.POINTER(_i64), _int, C.POINTER(_int)]),
     'pea_model_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
     'pea_conv_workspace_bytes': (_sz, [_vp, _int, _int, _int, _int, _int]),

@@ -170,6 +170,9 @@ class PEAStackFunction(torch.autograd.Function):
         engine.last_fused, stack = engine.forward(layer_params, x, att=att, masked=getattr(engine, 'fuse_masked', None),
                                                   want_stack=True, train=True)
         ctx.engine, ctx.n_slots = engine, n_slots
+        # engine.active_rows (set by the caller for ONE forward): the only rows of `stack` the loss will read, so the
+        # only rows whose gradient can be non-zero; the last layer's gradient gathers skip the others
+        ctx.active_rows, engine.active_rows = getattr(engine, 'active_rows', None), None
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
         ctx.present = [t is not None for t in flat]
         return stack
@@ -183,8 +186,16 @@ class PEAStackFunction(torch.autograd.Function):
             flat.append(next(it) if p else None)
         n_slots = ctx.n_slots
         layer_params = [tuple(flat[i:i + n_slots]) for i in range(0, len(flat), n_slots)]
+        lib = _lib.load()
+        mask = ctx.active_rows        # uint8 [N] or None: rows of the final outputs that can carry a gradient
         with torch.no_grad():
-            dx, grads = backward_conv_stack(ctx.engine, d_stack.contiguous(), x, layer_params)
+            if mask is not None:
+                _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, _lib.ptr(mask)))
+            try:
+                dx, grads = backward_conv_stack(ctx.engine, d_stack.contiguous(), x, layer_params)
+            finally:
+                if mask is not None:
+                    _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, None))
         out = []
         for lp, g in zip(layer_params, grads):
             for t, gt in zip(lp, g):

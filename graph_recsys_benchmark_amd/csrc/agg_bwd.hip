@@ -113,8 +113,11 @@ __global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
     const int row = valid ? P.short_rows[item] : 0;
     const bool active = valid && sl * 4 < P.W;
     const int c4 = active ? sl * 4 : 0;
+    // row_active (optional): rows whose output gradient is exactly zero (every row outside the BPR batch, for the last
+    // layer) contribute nothing: the D pass writes d a_dst = 0 for them without gathering, the S pass skips their edges
+    const bool row_on = !P.row_active || P.row_active[row] != 0;
     const int beg = P.rowptr[row];
-    const int end = valid ? P.rowptr[row + 1] : beg;
+    const int end = (valid && (MODE != AGG_GAT_BWD_D || row_on)) ? P.rowptr[row + 1] : beg;
     const int F4 = P.F / 4, pos = sl % F4;
     const bool pow2 = (F4 & (F4 - 1)) == 0;
     const int k = c4 / P.F;
@@ -129,20 +132,27 @@ __global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
             const float dz = dz_edge_d<F4T>(P, r, ld4(row_at(P.feat + c4, j, P.ld_feat)), lane, pos, F4, pow2);
             if (ok) dsum += dz;
         }
-        if (P.self_loop) dsum += dz_edge_d<F4T>(P, r, r.hself, lane, pos, F4, pow2);
-        if (active) finish_d(P, r, row, c4, dsum);
+        if (P.self_loop) {
+            const float dz = dz_edge_d<F4T>(P, r, r.hself, lane, pos, F4, pow2);
+            if (row_on) dsum += dz;
+        }
+        if (active) {
+            if (row_on) finish_d(P, r, row, c4, dsum);
+            else if (c4 % P.F == 0) P.ksum[(size_t)row * P.ld_k + k] = 0.f;
+        }
     } else {
         const RowS r = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float dzs = 0.f;
         for (int t = 0; t < len; ++t) {
-            const bool ok = beg + t < end;
-            const int i = ok ? P.col[beg + t] : 0;
+            bool ok = beg + t < end;
+            int i = ok ? P.col[beg + t] : 0;
+            if (P.row_active && ok && P.row_active[i] == 0) ok = false, i = 0;
             edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, i, P.ld_feat)), ld4(row_at(P.side + 4 * k, i, P.ld_side)), ok, lane, pos,
                         F4, pow2, acc, dzs);
         }
         if (P.self_loop)
-            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), true, lane,
+            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on, lane,
                         pos, F4, pow2, acc, dzs);
         if (active) finish_s(P, r, row, c4, acc, dzs);
     }
@@ -166,6 +176,11 @@ __global__ __launch_bounds__(kBlock) void bwd_long_kernel(const AggLaunch L) {
     const int F4 = P.F / 4, pos = sl % F4;
     const bool pow2 = (F4 & (F4 - 1)) == 0;
     const int k = c4 / P.F, nk = P.W / P.F;
+    const bool row_on = !P.row_active || P.row_active[row] != 0;  // see bwd_short_kernel
+    if (MODE == AGG_GAT_BWD_D && !row_on) {
+        if (it.slot < 0 && sub == 0 && active && c4 % P.F == 0) P.ksum[(size_t)row * P.ld_k + k] = 0.f;
+        return;  // hub chunks of such a row leave their partial records alone: the merge kernel does not read them
+    }
     RowD rd;
     RowS rs;
     if (MODE == AGG_GAT_BWD_D) rd = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
@@ -173,10 +188,22 @@ __global__ __launch_bounds__(kBlock) void bwd_long_kernel(const AggLaunch L) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
     int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
+    if (MODE == AGG_GAT_BWD_S && P.row_active && src >= 0 && P.row_active[src] == 0) src = -1;
     for (int base = it.beg; base < it.end; base += kWave) {
         const int nxt = base + kWave + lane;
-        const int src_next = nxt < it.end ? P.col[nxt] : -1;
-        const int cnt = min(kWave, it.end - base);
+        int src_next = nxt < it.end ? P.col[nxt] : -1;
+        if (MODE == AGG_GAT_BWD_S && P.row_active && src_next >= 0 && P.row_active[src_next] == 0) src_next = -1;
+        int cnt = min(kWave, it.end - base);
+        if (MODE == AGG_GAT_BWD_S && P.row_active) {
+            // pack the surviving edges of this batch of 64 to the front (order kept): the loop below then costs what
+            // the live edges cost, not what the row's degree costs
+            const unsigned long long live = __ballot(src >= 0);
+            const int n_live = __popcll(live);
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0));
+            const int dst = src >= 0 ? before : n_live + (lane - before);
+            src = __builtin_amdgcn_ds_permute(dst << 2, src);
+            cnt = n_live;
+        }
         for (int t = 0; t < cnt; t += NSG * U) {
             int jj[U];
             bool ok[U];
@@ -222,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void bwd_long_kernel(const AggLaunch L) {
         if (MODE == AGG_GAT_BWD_D) {
             dsum += dz_edge_d<F4T>(P, rd, rd.hself, lane, pos, F4, pow2);
         } else {
-            edge_s<F4T>(P, rs, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), true, lane,
+            edge_s<F4T>(P, rs, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on, lane,
                         pos, F4, pow2, acc, dsum);
         }
     }
@@ -249,6 +276,11 @@ __global__ __launch_bounds__(kBlock) void bwd_merge_kernel(const AggLaunch L) {
     const bool pow2 = (F4 & (F4 - 1)) == 0;
     const int k = c4 / P.F, nk = P.W / P.F;
     const size_t rec_sz = (size_t)(P.W + 2 * nk);
+    const bool row_on = !P.row_active || P.row_active[row] != 0;  // see bwd_short_kernel
+    if (MODE == AGG_GAT_BWD_D && !row_on) {
+        if (sub == 0 && active && c4 % P.F == 0) P.ksum[(size_t)row * P.ld_k + k] = 0.f;
+        return;
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
     for (int c = 0; c < count; ++c) {  // chunk order, every subgroup the same value
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void bwd_merge_kernel(const AggLaunch L) {
     } else {
         const RowS r = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
         if (P.self_loop)
-            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), true, lane,
+            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on, lane,
                         pos, F4, pow2, acc, dsum);
         if (sub == 0 && active) finish_s(P, r, row, c4, acc, dsum);
     }

@@ -157,6 +157,7 @@ struct AggGroup {
     float *side_out;       // D: writes the same record for its row
     float *ksum;           // D: d a_dst out / S: d a_src out, one float per head, stride ld_k
     const float *da_dst;   // S: d a_dst of the row (from the D pass), stride ld_k
+    const unsigned char *row_active;  // optional [N]: 0 = the row's output gradient is exactly zero (D: row, S: gathered row)
     int ld_g, ld_side, ld_k;
 };
 

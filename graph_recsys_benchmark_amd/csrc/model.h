@@ -64,6 +64,7 @@ struct pea_model {
     double alg_bytes = 0.0;
     bool single_conv = false;             // pea_*_conv: any output width, X goes to the caller's buffer
     bool backward = false;                // training buffers allocated
+    const unsigned char *active_rows = nullptr;  // pea_model_set_active_rows: rows with a non-zero final-output gradient
     std::vector<int> reverse_of;          // relation -> index of the reversed relation in the plan (-1: absent)
     size_t off_dx = 0, off_gpack = 0, gpack_floats = 0, off_colsum = 0;
 };

@@ -57,6 +57,12 @@ void fill_lists(AggGroup &a, const Relation &R) {
 
 using namespace pea;
 
+extern "C" int pea_model_set_active_rows(pea_model *m, const unsigned char *row_active) {
+    PEA_REQUIRE(m, PEA_ERR_ARG, "set_active_rows: null model");
+    m->active_rows = row_active;
+    return PEA_OK;
+}
+
 // phase 0: relu masks + bias gradients (all kinds); GAT/GCN: the aggregation backward -> dT_s (+ att gradients)
 // phase 1: SAGE only: reverse mean aggregation of dM_s (written by the host into the dT_s region) -> side_s region
 extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void *workspace, size_t workspace_bytes,
@@ -151,6 +157,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         a.ld_side = L.ld_side;
         a.ld_k = L.ld_k;
         a.ld_g = ldg;
+        a.row_active = g.last ? m->active_rows : nullptr;  // only the final outputs' gradient is known to be batch-sparse
         // D pass: destination rows of the forward relation, gathers T_j
         AggGroup D = a;
         fill_lists(D, R);

@@ -193,7 +193,7 @@ class PEABaseRecsysModel(GraphRecsysModel):
         """Differentiable forward: conv stack forward + backward in HIP, fusion (models/base.py:194-203) in torch ops."""
         eng = self._get_engine(train=True)
         flat = [t for lp in self._layer_params() for t in lp]
-        eng.fuse_att, eng.fuse_masked = None, None
+        eng.fuse_att, eng.fuse_masked, eng.active_rows = None, None, None
         stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
         out = self._fuse_torch(stack, metapath_idx)
         return (out, stack) if return_stack else out
@@ -219,10 +219,14 @@ class PEABaseRecsysModel(GraphRecsysModel):
         flat = [p for lp in self._layer_params() for p in lp]
         eng.fuse_att = self.att.detach().reshape(eng.P, eng.repr_dim) if self.channel_aggr == 'att' else None
         eng.fuse_masked = None
+        ids = t[:, :3].reshape(-1)
+        if self.kind == 'gat':                      # the stack is read at the batch's rows only: tell the backward
+            eng.active_rows = torch.zeros(self.x.shape[0], dtype=torch.uint8, device=t.device)
+            eng.active_rows[ids] = 1
         stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
         self.cached_repr, self._repr_partial = eng.last_fused, False
         b = t.shape[0]
-        rows = self._fuse_torch(stack[t[:, :3].reshape(-1)]).view(b, 3, -1)
+        rows = self._fuse_torch(stack[ids]).view(b, 3, -1)
 
         def score(i):
             return self.fc2(torch.relu(self.fc1(torch.cat([rows[:, 0], rows[:, i]], dim=-1))))

@@ -146,6 +146,11 @@ int pea_model_forward_train(pea_model *model, const float *const *params_host, c
 int pea_model_backward_level(pea_model *model, int level, int phase, void *workspace, size_t workspace_bytes,
                              void *stream);
 int pea_model_describe(const pea_model *model, int64_t *out_host, int max_len, int *needed_host);
+/* Optional hint for the next pea_model_backward_level calls (GAT): row_active [N] device bytes, 0 = the gradient of the
+ * row's FINAL conv output is exactly zero (a BPR step only touches the rows its batch names).  Such rows are skipped by
+ * the last layer's gradient gathers -- the result is the same sum with the zero terms left out.  NULL = every row.
+ * The buffer must stay valid until the backward calls have been issued; call again with NULL afterwards.            */
+int pea_model_set_active_rows(pea_model *model, const unsigned char *row_active);
 
 /* ---- dense half of the backward (the GEMMs the reference leaves to autograd: torch.nn.Linear / matmul inside the
  * PyG convs, graph_recsys_benchmark/models/base.py:138-139 under loss.backward(), solvers.py:214) -------------------
