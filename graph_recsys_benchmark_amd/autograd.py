@@ -50,7 +50,14 @@ def _view(wsf, off, n, ld):
     return wsf[off:off + n * ld].view(n, ld)
 
 
-def backward_conv_stack(engine, d_stack, x, layer_params):
+class _Slice:
+    """Placeholder for a gradient that lives in the packed reduction buffer (materialised once at the end)."""
+
+    def __init__(self, off, n, shape=None):
+        self.off, self.n, self.shape = off, n, shape
+
+
+def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
     """Gradients of sum(stack * d_stack) wrt x and every conv parameter.  Returns (dx, [tuple per layer])."""
     lib = _lib.load()
     if not engine.enable_backward:
@@ -68,10 +75,19 @@ def backward_conv_stack(engine, d_stack, x, layer_params):
     gpack = wsf[lay.off_gpack:lay.off_gpack + lay.pack_floats]
     # 1. gradient of the last-layer outputs, internal column order
     dX = _view(wsf, lay.off_dx, n, lay.ld_x)
-    for lv in lay.levels:
-        for u in lv['units']:
-            if u['last']:
-                dX[:, u['o_col']:u['o_col'] + u['HF']] = d_stack[:, u['p'], :]
+    if active_ids is not None:
+        # d_stack is zero outside the rows the loss read: clear once, then move those rows only
+        dX.zero_()
+        rows = d_stack[active_ids]                                              # [B', P, R]
+        for lv in lay.levels:
+            for u in lv['units']:
+                if u['last']:
+                    dX[active_ids, u['o_col']:u['o_col'] + u['HF']] = rows[:, u['p'], :]
+    else:
+        for lv in lay.levels:
+            for u in lv['units']:
+                if u['last']:
+                    dX[:, u['o_col']:u['o_col'] + u['HF']] = d_stack[:, u['p'], :]
     stream = _lib.current_stream()
 
     def level_call(level, phase):
@@ -96,7 +112,7 @@ def backward_conv_stack(engine, d_stack, x, layer_params):
                 M = T[:, u['t_col']:u['t_col'] + u['in_w']]
                 In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
                 grads[li][0], grads[li][2] = grad_weight([(G, M), (G, In)])
-                grads[li][1] = gpack[u['bias_off']:u['bias_off'] + u['HF']].clone()
+                grads[li][1] = _Slice(u['bias_off'], u['HF'])
                 dT[:, u['t_col']:u['t_col'] + u['in_w']] += G @ w_rel          # level 0: channels of one relation share M
                 direct = G @ w_root
                 if s == 0:
@@ -149,12 +165,20 @@ def backward_conv_stack(engine, d_stack, x, layer_params):
             if kind == 'gat':
                 grads[li][0] = dW_all[u['t_col']:u['t_col'] + u['HF']] if s == 0 else dWs[q]
                 shape = layer_params[li][1].shape
-                grads[li][1] = gpack[lv['att_dst_off'] + u['t_col']:lv['att_dst_off'] + u['t_col'] + u['HF']].clone().view(shape)
-                grads[li][2] = gpack[lv['att_src_off'] + u['t_col']:lv['att_src_off'] + u['t_col'] + u['HF']].clone().view(shape)
-                grads[li][3] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
+                grads[li][1] = _Slice(lv['att_dst_off'] + u['t_col'], u['HF'], shape)
+                grads[li][2] = _Slice(lv['att_src_off'] + u['t_col'], u['HF'], shape)
+                grads[li][3] = _Slice(lv['bias_off'] + u['t_col'], u['HF'])
             else:
                 grads[li][0] = dW_all[:, u['t_col']:u['t_col'] + u['HF']] if s == 0 else dWs[q]
-                grads[li][1] = gpack[lv['bias_off'] + u['t_col']:lv['bias_off'] + u['t_col'] + u['HF']].clone()
+                grads[li][1] = _Slice(lv['bias_off'] + u['t_col'], u['HF'])
+    # the small (bias / attention-vector) gradients were reduced into the packed buffer level by level: one copy of it,
+    # then views (the workspace itself is overwritten by the next step)
+    packed = gpack.clone()
+    for g in grads:
+        for q, item in enumerate(g):
+            if isinstance(item, _Slice):
+                t = packed[item.off:item.off + item.n]
+                g[q] = t if item.shape is None else t.view(item.shape)
     return dx, grads
 
 
@@ -173,6 +197,7 @@ class PEAStackFunction(torch.autograd.Function):
         # engine.active_rows (set by the caller for ONE forward): the only rows of `stack` the loss will read, so the
         # only rows whose gradient can be non-zero; the last layer's gradient gathers skip the others
         ctx.active_rows, engine.active_rows = getattr(engine, 'active_rows', None), None
+        ctx.active_ids, engine.active_ids = getattr(engine, 'active_ids', None), None
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
         ctx.present = [t is not None for t in flat]
         return stack
@@ -192,7 +217,7 @@ class PEAStackFunction(torch.autograd.Function):
             if mask is not None:
                 _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, _lib.ptr(mask)))
             try:
-                dx, grads = backward_conv_stack(ctx.engine, d_stack.contiguous(), x, layer_params)
+                dx, grads = backward_conv_stack(ctx.engine, d_stack.contiguous(), x, layer_params, ctx.active_ids)
             finally:
                 if mask is not None:
                     _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, None))

@@ -193,7 +193,7 @@ class PEABaseRecsysModel(GraphRecsysModel):
         """Differentiable forward: conv stack forward + backward in HIP, fusion (models/base.py:194-203) in torch ops."""
         eng = self._get_engine(train=True)
         flat = [t for lp in self._layer_params() for t in lp]
-        eng.fuse_att, eng.fuse_masked, eng.active_rows = None, None, None
+        eng.fuse_att, eng.fuse_masked, eng.active_rows, eng.active_ids = None, None, None, None
         stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
         out = self._fuse_torch(stack, metapath_idx)
         return (out, stack) if return_stack else out
@@ -223,6 +223,7 @@ class PEABaseRecsysModel(GraphRecsysModel):
         if self.kind == 'gat':                      # the stack is read at the batch's rows only: tell the backward
             eng.active_rows = torch.zeros(self.x.shape[0], dtype=torch.uint8, device=t.device)
             eng.active_rows[ids] = 1
+        eng.active_ids = ids                        # ... and where d_stack can be non-zero (every kind)
         stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
         self.cached_repr, self._repr_partial = eng.last_fused, False
         b = t.shape[0]
