@@ -92,6 +92,7 @@ struct Relation {
     int *slot_of_node = nullptr;                       // device [N], -1 = not a source
     int *need_rows = nullptr;                          // device: rows whose level-0 transform this rank computes
     int64_t n_need = 0;
+    unsigned long long need_hash = 0;                  // FNV-1a of need_rows (equal lists -> one shared transform job)
 };
 
 }  // namespace pea

@@ -561,8 +561,17 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             size_t i = 0;
             while (i < L.units.size()) {
                 size_t j = i;
-                while (j < L.units.size() && L.units[j].rel == L.units[i].rel) ++j;
                 const Relation &R = plan->rels[(size_t)L.units[i].rel];
+                // one job per run of channels whose relations read the same row list (same relation, or relations
+                // the host gave one shared list: own rows + the union of their few source nodes) and whose columns are
+                // contiguous: wider jobs reuse the input fragment over more column tiles
+                while (j < L.units.size()) {
+                    const Relation &Rj = plan->rels[(size_t)L.units[j].rel];
+                    const bool same_rows = L.units[j].rel == L.units[i].rel || (Rj.n_need == R.n_need && Rj.need_hash == R.need_hash);
+                    const bool contiguous = j == i || L.units[j].t_col == L.units[j - 1].t_col + L.units[j - 1].HF;
+                    if (!same_rows || !contiguous) break;
+                    ++j;
+                }
                 PEA_REQUIRE(R.need_rows != nullptr || R.n_need == 0, PEA_ERR_ARG, "relation %d has no need_rows (pea_plan_set_sources)", L.units[i].rel);
                 const int c_beg = L.units[i].t_col, c_end = L.units[j - 1].t_col + L.units[j - 1].HF;
                 GemmJob J{};

@@ -487,7 +487,14 @@ extern "C" int pea_plan_set_sources(pea_plan *plan, int relation, const int32_t 
                            R.slot_of_node, R.col_slot, err);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, stream);
+    // content hash of the row list: relations handed the SAME list share one first-layer transform job (model.hip)
+    std::vector<int> host_rows((size_t)n_need);
+    if (e == hipSuccess && n_need > 0)
+        e = hipMemcpyAsync(host_rows.data(), R.need_rows, (size_t)n_need * sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    unsigned long long hsh = 1469598103934665603ull;  // FNV-1a
+    for (int v : host_rows) hsh = (hsh ^ (unsigned long long)(unsigned)v) * 1099511628211ull;
+    R.need_hash = hsh;
     (void)hipFree(err);
     PEA_REQUIRE(e == hipSuccess, PEA_ERR_HIP, "set_sources: %s", hipGetErrorString(e));
     PEA_REQUIRE(herr == 0, PEA_ERR_ARG, "set_sources: a source node of relation %d has no slot", relation);

@@ -100,8 +100,16 @@ class GraphPlan:
         if self.shard[1] > 1:
             own = self.layout.owned_rows(self.device).to(torch.int32).contiguous()
             _lib.check(lib.pea_plan_set_owned_rows(handle, _lib.ptr(own), own.numel(), _lib.current_stream()))
-            for r, ei in enumerate(uniq):
-                lay = self.layout.source_layout(ei)
+            lays = [self.layout.source_layout(ei) for ei in uniq]
+            # relations with few source nodes (attribute -> item ...) share ONE first-layer row list: own rows + the
+            # union of their sources, so their channels' transforms run as one wide job (a few extra rows, same results)
+            small = [r for r, lay in enumerate(lays) if lay.src_nodes.numel() * 10 <= own.numel()]
+            if len(small) > 1:
+                shared = torch.unique(torch.cat([self.layout.owned_rows(self.device)] +
+                                                [lays[r].src_nodes for r in small])).to(torch.int32)
+                for r in small:
+                    lays[r].need_rows = shared
+            for r, lay in enumerate(lays):
                 need = lay.need_rows.contiguous()
                 _lib.check(lib.pea_plan_set_sources(handle, r, _lib.ptr(lay.slot_of_node.contiguous()), lay.slots_per_rank,
                                                     _lib.ptr(need), need.numel(), _lib.current_stream()))
