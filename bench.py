@@ -199,9 +199,15 @@ def main():
     # around every kernel launch (on the launch stream) for the per-kernel roofline
     dt, loss = timed_region(False)
     prof, dt_prof = {}, None
+    comm_ms = None
     if profile:
+        from graph_recsys_benchmark_amd.sharding import CommTimer
+        CommTimer.enabled, CommTimer.events = world > 1, []
         dt_prof, loss = timed_region(True)
         prof = read_profile()
+        if world > 1:                      # device time between the start and the end of every collective, this rank
+            comm_ms = CommTimer.total_ms() / args.steps
+        CommTimer.enabled = False
 
     eng = model._engine
     messages = eng.messages
@@ -223,6 +229,7 @@ def main():
                    'parallelism': 'rows%d' % world if world > 1 else 'single', 'loss': float(loss)},
         'bpr_triples_per_s': b / (dt / args.steps),
         'ms_per_step_with_kernel_events': None if dt_prof is None else dt_prof / args.steps * 1e3,
+        'exchange_ms_per_step': comm_ms,   # N > 1: stream time inside the collectives (rank 0), from the profiled pass
         'forward_roofline': {'algorithmic_bytes_per_step': alg_bytes,
                              'achieved_GBs': alg_bytes / (dt / args.steps) / 1e9,
                              'frac_of_8TBs': alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world},

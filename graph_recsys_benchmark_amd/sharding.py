@@ -18,6 +18,28 @@ import torch
 import torch.distributed as dist
 
 
+class CommTimer:
+    """Optional device-time accounting of the exchanges (bench.py): pairs of CUDA events around every collective of
+    this process, read back after a synchronize.  Off by default."""
+    enabled = False
+    events = []
+
+    @classmethod
+    def span(cls, device):
+        if not cls.enabled or not torch.cuda.is_available() or torch.device(device).type != 'cuda':
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cls.events.append((a, b))
+        a.record()
+        return b
+
+    @classmethod
+    def total_ms(cls):
+        ms = sum(a.elapsed_time(b) for a, b in cls.events)
+        cls.events = []
+        return ms
+
+
 class SourceLayout:
     """Exchange layout of one relation's source rows."""
 
@@ -75,6 +97,7 @@ class ShardLayout:
         if self.world == 1 or block_rows == 0 or self.dry:
             return
         mine = buf[self.rank * block_rows:(self.rank + 1) * block_rows]
+        done = CommTimer.span(buf.device)
         if dist.get_backend(group) == 'nccl':
             # RCCL all-gather; the send block is copied out first so input and output never alias
             dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1).clone(), group=group)
@@ -84,6 +107,8 @@ class ShardLayout:
             for r, p in enumerate(parts):
                 if r != self.rank:
                     buf[r * block_rows:(r + 1) * block_rows].copy_(p)
+        if done is not None:
+            done.record()
 
     def exchange_sources(self, xbuf, table, layout, col, width, group=None):
         """xbuf [world*M, ld] <- all-gather of table[owner's source nodes, col:col+width] (slot order)."""
@@ -105,12 +130,16 @@ class ShardLayout:
         rows = torch.where(mine.view(-1, *([1] * (rows.dim() - 1))), rows, torch.zeros((), dtype=rows.dtype, device=rows.device))
         if self.dry:
             return rows
+        done = CommTimer.span(rows.device)
         if dist.get_backend(group) == 'nccl':
             dist.all_reduce(rows, group=group)
-            return rows
-        host = rows.detach().cpu()
-        dist.all_reduce(host, group=group)
-        return host.to(rows.device)
+        else:
+            host = rows.detach().cpu()
+            dist.all_reduce(host, group=group)
+            rows = host.to(rows.device)
+        if done is not None:
+            done.record()
+        return rows
 
     def allgather_rows(self, table, group=None):
         """table [N, ...]: every rank has written the rows it owns; fills in everybody else's (in place)."""
