@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--scale', type=float, default=1.0, help='edge/node count multiplier (tests only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event roofline leg')
+    ap.add_argument('--graph', action='store_true', help='N=1 only: replay the forward from a captured hipGraph\n'
+                    '(PEAEngine.forward_graphed; for launch-bound presets such as ml_small)')
     ap.add_argument('--train-steps', type=int, default=0, help='also time this many full training steps '
                     '(zero_grad, loss, backward, Adam step: reference solvers.py:213-216); extra field, N=1 only')
     ap.add_argument('--emulate-world', type=int, default=0, help='single process: time ONE rank (rank 0) of a sharded run of\n'
@@ -151,6 +153,11 @@ def main():
 
     def step():
         with torch.no_grad():
+            if args.graph and world == 1 and args.emulate_world <= 1:
+                eng = model._get_engine()
+                model.cached_repr = eng.forward_graphed(model._layer_params(), model.x.detach(), att=getattr(model, 'att', None))
+                from graph_recsys_benchmark_amd.engine import bpr_score
+                return bpr_score(model.cached_repr, batch, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias)
             return model.loss(batch)
 
     for _ in range(args.warmup):

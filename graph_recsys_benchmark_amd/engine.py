@@ -200,7 +200,7 @@ class PEAEngine:
                     row.append((d, src, dst, plan.source_layouts[d.relation]))
                 self._exchanges.append(row)
 
-    def forward(self, layer_params, x, att=None, masked=None, want_stack=False, train=False, gather=True):
+    def forward(self, layer_params, x, att=None, masked=None, want_stack=False, train=False, gather=True, out=None):
         """layer_params: list (channel-major, then step) of tuples of tensors in PARAM_SLOTS order
         (a missing bias may be None).  train=True keeps what backward() needs (single GPU).  gather=False (sharded
         plans only): skip the final all-gather; only the rows this rank owns are defined in the result."""
@@ -233,7 +233,8 @@ class PEAEngine:
                 raise ValueError("att is required for channel_aggr='att'")
             att_t = att.detach().reshape(self.P, self.repr_dim).contiguous()
             keep.append(att_t)
-        out = torch.empty((n, self.repr_dim), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((n, self.repr_dim), dtype=torch.float32, device=x.device)
         stack = torch.empty((n, self.P, self.repr_dim), dtype=torch.float32, device=x.device) if want_stack else None
         m = -1 if masked is None else int(masked)
         if not self.sharded:
@@ -259,6 +260,25 @@ class PEAEngine:
             if want_stack:
                 shard.allgather_rows(stack)
         return (out, stack) if want_stack else out
+
+    def forward_graphed(self, layer_params, x, att=None, masked=None):
+        """forward() with the launches of the schedule captured ONCE into a hipGraph and replayed while the argument
+        pointers stay the same (parameters are updated in place by the optimizer, so a training loop keeps replaying):
+        for launch-bound sizes (MovieLens latest-small: ~13 launches of 10-40 us each).  Unsharded, no stack.  The
+        returned tensor is a static buffer that the next call overwrites."""
+        if self.sharded:
+            raise NotImplementedError('the graphed forward is single-GPU')
+        key = (x.data_ptr(), None if att is None else att.data_ptr(), masked,
+               tuple(None if t is None else t.data_ptr() for lp in layer_params for t in lp))
+        if getattr(self, '_graph_key', None) != key:
+            self._graph_out = self.forward(layer_params, x, att=att, masked=masked).clone()   # warm-up: attributes, lazy state
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.forward(layer_params, x, att=att, masked=masked, out=self._graph_out)
+            self._graph, self._graph_key = graph, key
+        self._graph.replay()
+        return self._graph_out
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None

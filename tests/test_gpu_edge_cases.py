@@ -91,3 +91,23 @@ def test_error_codes_and_messages():
         GraphPlan(4, [[ei.to(torch.int32)]], True)
     with pytest.raises(RuntimeError):
         GraphPlan(4, [[ei.cpu()]], True)
+
+
+def test_graphed_forward_replays_the_same_result():
+    """PEAEngine.forward_graphed: the schedule captured into a hipGraph gives the eager result bit for bit, and keeps
+    doing so after the parameters were changed in place (what an optimizer step does)."""
+    from helpers import GoldenCase, model_from_golden
+    g = GoldenCase('pea_gat_p5s2_h1_att')
+    model = model_from_golden(g)
+    model.eval()
+    eng = model._get_engine()
+    with torch.no_grad():
+        params, x, att = model._layer_params(), model.x.detach(), model.att
+        want = eng.forward(params, x, att=att).clone()
+        got = eng.forward_graphed(params, x, att=att)
+        assert torch.equal(got, want)
+        for p in model.parameters():
+            p.mul_(1.01)
+        want2 = eng.forward(params, x, att=att).clone()
+        got2 = eng.forward_graphed(params, x, att=att)
+        assert got2.data_ptr() == got.data_ptr() and torch.equal(got2, want2) and not torch.equal(want2, want)
