@@ -245,10 +245,15 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         name, (launches, ms, units) = dom
         achieved = units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = load_traffic(name)
         out['roofline'] = {'bound': 'hbm', 'kernel': name, 'launches': launches,
                            'avg_launch_ms': ms / launches, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(name),
-                           'algorithmic_bytes_per_launch': units / launches}
+                           'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                           'algorithmic_bytes_per_launch': units / launches,
+                           # the committed PMC traffic of this kernel over its live duration: what the fabric really moved
+                           # (algorithmic bytes count the reference's per-channel re-reads, so `frac` can exceed 1)
+                           'traffic_GBs': None if not traffic or world > 1 else traffic / (ms / launches * 1e-3) / 1e9,
+                           'traffic_frac': None if not traffic or world > 1 else traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out['kernels_ms_per_step'] = {k: round(v[1] / args.steps, 4) for k, v in
                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}
     if world == 1 and args.train_steps > 0:
