@@ -27,6 +27,13 @@
  *     function synchronises the device except pea_plan_create (one-time graph preprocessing).
  *   - fp32 features, int64 ids at the surface (values < num_nodes < 2^31; the plan narrows to int32).
  *   - Handles are immutable after creation and may be used from one stream at a time.
+ *   - One device per process (the deployment model is one process per GPU, torch.distributed.run): per-kernel
+ *     attributes and the CU count are cached per process after the first launch.
+ *
+ *   pea_model_forward_train / _backward_level, pea_grad_weight, pea_dense_batch
+ *                       solvers.py:213-216 (loss.backward() through the convs: sparse half / dense half)
+ *   pea_weighted_aggregate   nn/kgat_conv.py:36-44, nn/kgcn_conv.py:32-37, nn/ngcf_conv.py:42-45 (message + scatter)
+ *   pea_sample_negatives     datasets/movielens.py:920-940 (an on-GPU sampler NEXT TO the bit-exact host mirror)
  */
 #ifndef PEAHIP_H_
 #define PEAHIP_H_
