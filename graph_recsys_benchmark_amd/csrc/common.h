@@ -200,6 +200,10 @@ struct GemmJob {
     // row set of the launch
     const int *rows;
     int64_t n_rows;
+    // 1: never route this job to the narrow-output kernel.  The kernels differ in k summation order, so a transform must
+    // pick its kernel from properties that do not depend on how jobs were cut: the first-layer (shared-input) jobs are
+    // merged per relation when sharded and all together on one GPU, and both must give the same bits.
+    int no_narrow;
 };
 int launch_gemm(const GemmJob &job, const int *rows, int64_t n_rows, hipStream_t stream);
 int launch_gemm_batch(const GemmJob *jobs, int n_jobs, const int *rows, int64_t n_rows, hipStream_t stream);

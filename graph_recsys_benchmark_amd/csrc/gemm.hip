@@ -495,7 +495,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmBatch Bt, co
 
 // a job qualifies when its output is at most 16 columns wide, k fits 128 and every segment can take float4 stores
 static bool skinny_ok(const GemmJob &J) {
-    if (J.n_out > 16 || J.K1 + J.K2 > 128 || J.ldb < J.n_out) return false;
+    if (J.no_narrow || J.n_out > 16 || J.K1 + J.K2 > 128 || J.ldb < J.n_out) return false;
     for (int sg = 0; sg < J.n_seg; ++sg) {
         const GemmSegment &S = J.seg[sg];
         if (S.c0 % 4 || S.c1 % 4 || S.ld % 4 || (reinterpret_cast<uintptr_t>(S.dst) & 15)) return false;

@@ -552,6 +552,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             J.seg[0].c1 = L.n_cols;
             J.seg[0].dst = T;
             J.seg[0].ld = L.ld_t;
+            J.no_narrow = 1;  // same kernel family as the per-relation jobs of a sharded plan (bit-identical results)
             return launch_gemm(J, nullptr, N, stream);
         }
         if (L.shared_input) {
@@ -586,6 +587,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 J.seg[0].c1 = c_end - c_beg;
                 J.seg[0].dst = T + c_beg;
                 J.seg[0].ld = L.ld_t;
+                J.no_narrow = 1;
                 J.rows = R.need_rows;       // one launch for all relations, each job with its own row list
                 J.n_rows = R.n_need;
                 rel_jobs.push_back(J);

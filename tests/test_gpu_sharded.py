@@ -26,7 +26,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, kind, heads):
+def _worker(rank, world, port, kind, heads, hidden=32, repr_dim=16):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -40,7 +40,7 @@ def _worker(rank, world, port, kind, heads):
         if heads == 1:                      # a 1-step channel only stacks with num_heads = 1 (models/base.py:196)
             edges.append([a2i])
             steps.append(1)
-        model = build_model(kind, n, edges, steps, 32, 32, 16, heads=heads)
+        model = build_model(kind, n, edges, steps, 32, hidden, repr_dim, heads=heads)
         model.load_state_dict(random_state_dict(model, 9))
         model.eval()
         with torch.no_grad():
@@ -78,6 +78,14 @@ def _worker(rank, world, port, kind, heads):
 @pytest.mark.parametrize('kind,heads,world', [('gat', 1, 2), ('gat', 2, 3), ('gcn', 1, 2), ('sage', 1, 3)])
 def test_sharded_forward_is_bit_exact(kind, heads, world):
     mp.spawn(_worker, args=(world, _free_port(), kind, heads), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize('kind,hidden,repr_dim', [('gcn', 8, 8), ('gat', 8, 16), ('sage', 4, 12)])
+def test_sharded_narrow_layers_are_bit_exact(kind, hidden, repr_dim):
+    """Layers of <= 16 output columns: the per-relation first-layer jobs of a sharded plan and the single merged job of
+    the one-GPU plan must run the same kernel family (the narrow-output kernel sums k in another order) -- found by
+    profiles/tools/fuzz_sharded.py."""
+    mp.spawn(_worker, args=(2, _free_port(), kind, 1, hidden, repr_dim), nprocs=2, join=True)
 
 
 def _rccl_worker(rank, world, port):
