@@ -81,20 +81,55 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     if (MODE == AGG_GAT) {
         for (int off = G; off < kWave; off <<= 1) len = max(len, __shfl_xor(len, off));
     }
-    for (int t = 0; t < len; ++t) {
-        const int e = beg + t;
-        const bool ok = e < end;
-        const int j = ok ? P.col[e] : 0;
-        const float4 h = ld4(row_at(feat, j, P.ld_feat));
+    constexpr int U = 4;  // edges in flight per subgroup: U ids, then U gathered rows, then one softmax update for the U
+    for (int t = 0; t < len; t += U) {
+        int jj[U];
+        bool ok[U];
+        float4 h[U];
+        float a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = beg + t + u;
+            ok[u] = e < end;
+            jj[u] = ok[u] ? P.col[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
+            if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
+            if (MODE == AGG_WSUM) a[u] = ok[u] ? P.edge_w[P.eid[beg + t + u]] : 0.f;
+        }
         if (MODE == AGG_GAT) {
-            const float a = head_sum<F4T>(dot4(h, att_s), lane, pos, F4, pow2);
-            if (ok) st.push(leaky(a + a_d, P.neg_slope), h);
-        } else if (MODE == AGG_GCN) {
-            sum = fma4(P.dinv[j] * di, h, sum);
-        } else if (MODE == AGG_WSUM) {
-            sum = fma4(P.edge_w[P.eid[e]], h, sum);
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] = head_sum<F4T>(dot4(h[u], att_s), lane, pos, F4, pow2);
+            float e[U];
+            float mn = st.m;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                e[u] = ok[u] ? leaky(a[u] + a_d, P.neg_slope) : -INFINITY;  // 2^(-inf - m) = 0
+                mn = fmaxf(mn, e[u]);
+            }
+            const float fs = __builtin_amdgcn_exp2f(st.m - mn);
+            st.m = mn;
+            st.s *= fs;
+            st.acc = scale4(st.acc, fs);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = __builtin_amdgcn_exp2f(e[u] - mn);  // 0 for the masked slots (mn is finite)
+                st.s += p;
+                st.acc = fma4(p, h[u], st.acc);
+            }
         } else {
-            sum = add4(sum, h);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (MODE == AGG_GCN) {
+                    sum = fma4(ok[u] ? a[u] * di : 0.f, h[u], sum);
+                } else if (MODE == AGG_WSUM) {
+                    sum = fma4(a[u], h[u], sum);
+                } else {
+                    if (ok[u]) sum = add4(sum, h[u]);
+                }
+            }
         }
     }
     if (P.self_loop) {
