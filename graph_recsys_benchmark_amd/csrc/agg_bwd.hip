@@ -126,11 +126,21 @@ __global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
     if (MODE == AGG_GAT_BWD_D) {
         const RowD r = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
         float dsum = 0.f;
-        for (int t = 0; t < len; ++t) {
-            const bool ok = beg + t < end;
-            const int j = ok ? P.col[beg + t] : 0;
-            const float dz = dz_edge_d<F4T>(P, r, ld4(row_at(P.feat + c4, j, P.ld_feat)), lane, pos, F4, pow2);
-            if (ok) dsum += dz;
+        constexpr int U = 4;  // edges in flight per subgroup (ids, then rows, then the arithmetic), as in agg_short_kernel
+        for (int t = 0; t < len; t += U) {
+            bool ok[U];
+            float4 h[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = beg + t + u < end;
+                const int j = ok[u] ? P.col[beg + t + u] : 0;
+                h[u] = ld4(row_at(P.feat + c4, j, P.ld_feat));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float dz = dz_edge_d<F4T>(P, r, h[u], lane, pos, F4, pow2);
+                if (ok[u]) dsum += dz;
+            }
         }
         if (P.self_loop) {
             const float dz = dz_edge_d<F4T>(P, r, r.hself, lane, pos, F4, pow2);
@@ -144,12 +154,20 @@ __global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
         const RowS r = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float dzs = 0.f;
-        for (int t = 0; t < len; ++t) {
-            bool ok = beg + t < end;
-            int i = ok ? P.col[beg + t] : 0;
-            if (P.row_active && ok && P.row_active[i] == 0) ok = false, i = 0;
-            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, i, P.ld_feat)), ld4(row_at(P.side + 4 * k, i, P.ld_side)), ok, lane, pos,
-                        F4, pow2, acc, dzs);
+        constexpr int U = 4;
+        for (int t = 0; t < len; t += U) {
+            bool ok[U];
+            float4 g[U], sd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = beg + t + u < end;
+                int i = ok[u] ? P.col[beg + t + u] : 0;
+                if (P.row_active && ok[u] && P.row_active[i] == 0) ok[u] = false, i = 0;
+                g[u] = ld4(row_at(P.feat + c4, i, P.ld_feat));
+                sd[u] = ld4(row_at(P.side + 4 * k, i, P.ld_side));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) edge_s<F4T>(P, r, g[u], sd[u], ok[u], lane, pos, F4, pow2, acc, dzs);
         }
         if (P.self_loop)
             edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on, lane,
