@@ -54,7 +54,10 @@ constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kShortDeg = 32;      // rows with <= this many kept edges go to the row-per-subgroup kernel
 constexpr int kChunk = 512;        // hub rows are cut into chunks of at most this many edges
 constexpr int64_t kSliceMinEdges = 2000000;   // relations below this are never source-sliced
-constexpr double kSliceBytes = 2.5e6;         // target gather footprint of one source slice (an XCD's L2 is 4 MiB)
+// target gather footprint of one source slice.  An XCD's L2 is 4 MiB, but fewer, larger slices win: on the 42 MB user
+// table of the 25m-shaped graph 8 slices of 5.2 MB (one per XCD, one phase) beat 16 x 2.6 MB and 24 x 1.7 MB (0.53 vs 0.55
+// vs 0.57 ms for the first-layer gather; unsliced: 0.89 ms) -- every extra slice cuts the hub rows into more segments
+constexpr double kSliceBytes = 6.0e6;
 constexpr int kSliceMinSegment = 32;          // only rows with >= slices*this edges are cut per slice
 
 // One work item of the row-per-wave kernel: edges [beg, end) of `row`; slot < 0 writes the output row,
