@@ -263,6 +263,8 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
     std::vector<LongItem> items;
     const int tile = plan->shard_tile, world = plan->shard_world, rank = plan->shard_rank;
     int max_deg = 0, slots = 0;
+    const int short_deg = getenv("PEA_SHORT_DEG") ? atoi(getenv("PEA_SHORT_DEG")) : kShortDeg;  // tuning knobs
+    const int chunk = getenv("PEA_CHUNK") ? atoi(getenv("PEA_CHUNK")) : kChunk;
     for (int64_t i = 0; i < N; ++i) {
         const int deg = rp[(size_t)i + 1] - rp[(size_t)i];
         max_deg = std::max(max_deg, deg);
@@ -271,15 +273,15 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
         R.edges_owned += deg;
         if (deg == 0) {
             zero_rows.push_back((int)i);
-        } else if (deg <= kShortDeg) {
+        } else if (deg <= short_deg) {
             short_rows.push_back((int)i);
             R.edges_short += deg;
-        } else if (deg <= kChunk) {
+        } else if (deg <= chunk) {
             items.push_back({(int)i, rp[(size_t)i], rp[(size_t)i + 1], -1});
         } else if (S > 1 && deg >= S * kSliceMinSegment) {
             sliced_rows.push_back((int)i);  // chunked per source slice below
         } else {
-            const int nch = (deg + kChunk - 1) / kChunk;
+            const int nch = (deg + chunk - 1) / chunk;
             const int len = (deg + nch - 1) / nch;
             hub_rows.push_back((int)i);
             hub_first.push_back(slots);
@@ -326,7 +328,7 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
             for (int sl = 0; sl < S; ++sl) {
                 const int b0 = bounds[(size_t)h * (S + 1) + sl], e0 = bounds[(size_t)h * (S + 1) + sl + 1];
                 if (e0 <= b0) continue;
-                const int nch = (e0 - b0 + kChunk - 1) / kChunk, len = (e0 - b0 + nch - 1) / nch;
+                const int nch = (e0 - b0 + chunk - 1) / chunk, len = (e0 - b0 + nch - 1) / nch;
                 for (int c = 0; c < nch; ++c) {
                     const int b = b0 + c * len;
                     per_slice[(size_t)sl].push_back({sliced_rows[(size_t)h], b, std::min(b + len, e0), slots++});
