@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     const int F4 = P.F / 4, pos = sl % F4;
     const bool pow2 = (F4 & (F4 - 1)) == 0;
     float a_d = 0.f, di = 0.f;
+    const float slope = P.neg_slope;  // kept in a register: read inside the edge loop it became a scalar load + wait per edge
     float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
         att_s = ld4(P.att_src + c4);
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
             float mn = st.m;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                e[u] = ok[u] ? leaky(a[u] + a_d, P.neg_slope) : -INFINITY;  // 2^(-inf - m) = 0
+                const float z = leaky(a[u] + a_d, slope);                   // computed for every slot, then selected:
+                e[u] = ok[u] ? z : -INFINITY;                                // no branch, 2^(-inf - m) = 0
                 mn = fmaxf(mn, e[u]);
             }
             const float fs = __builtin_amdgcn_exp2f(st.m - mn);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
     if (P.self_loop) {
         if (MODE == AGG_GAT) {
             const float a = head_sum<F4T>(dot4(h_self, att_s), lane, pos, F4, pow2);
-            st.push(leaky(a + a_d, P.neg_slope), h_self);
+            st.push(leaky(a + a_d, slope), h_self);
         } else if (MODE == AGG_GCN) {
             sum = fma4(di * di, ld4(row_at(feat_self, row, P.ld_self)), sum);
         }
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     const int F4 = P.F / 4, pos = sl % F4;
     const bool pow2 = (F4 & (F4 - 1)) == 0;
     float a_d = 0.f, di = 0.f;
+    const float slope = P.neg_slope;  // kept in a register: read inside the edge loop it became a scalar load + wait per edge
     float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
     if (MODE == AGG_GAT) {
         att_s = ld4(P.att_src + c4);
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
                 float mn = st.m;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    e[u] = ok[u] ? leaky(a[u] + a_d, P.neg_slope) : -INFINITY;  // 2^(-inf - m) = 0
+                    const float z = leaky(a[u] + a_d, slope);                   // computed for every slot, then selected:
+                e[u] = ok[u] ? z : -INFINITY;                                // no branch, 2^(-inf - m) = 0
                     mn = fmaxf(mn, e[u]);
                 }
                 const float fs = __builtin_amdgcn_exp2f(st.m - mn);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     if (P.self_loop) {
         if (MODE == AGG_GAT) {
             const float a = head_sum<F4T>(dot4(h_self, att_s), lane, pos, F4, pow2);
-            st.push(leaky(a + a_d, P.neg_slope), h_self);
+            st.push(leaky(a + a_d, slope), h_self);
         } else if (MODE == AGG_GCN) {
             sum = fma4(di * di, ld4(row_at(feat_self, row, P.ld_self)), sum);
         }
