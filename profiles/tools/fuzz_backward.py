@@ -55,11 +55,12 @@ def one(rng, i):
         sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         want_loss, want = f64_loss_and_grads(kind, sd, edges, steps, heads, aggr, batch)
         assert abs(float(loss) - want_loss) <= 5e-5 * max(abs(want_loss), 1.0), 'loss %r vs %r' % (float(loss), want_loss)
-        for name, p in model.named_parameters():
+        top = max(float(np.abs(w).max()) for w in want.values())     # a gradient that is exactly 0 in float64 (e.g. d att_i when
+        for name, p in model.named_parameters():                       # every logit of a row has one sign) is fp32 noise here
             g, w = p.grad.detach().cpu().numpy().astype(np.float64), want[name]
             scale = max(np.abs(w).max(), 1e-12)
             err = np.abs(g - w).max()
-            assert err <= 5e-4 * scale + 1e-8, '%s: max err %.3e vs scale %.3e' % (name, err, scale)
+            assert err <= 5e-4 * scale + 1e-6 * top + 1e-8, '%s: max err %.3e vs scale %.3e (largest gradient %.3e)' % (name, err, scale, top)
         return True, desc
     except Exception:
         return False, desc + '\n' + traceback.format_exc(limit=2)
