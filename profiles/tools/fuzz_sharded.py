@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def worker(rank, world, port, count, seed):
+def worker(rank, world, port, count, seed, strict=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from helpers import build_model, random_state_dict
@@ -79,7 +79,11 @@ def worker(rank, world, port, count, seed):
         del model
     if rank == 0:
         print('%d / %d failed (world %d)' % (bad, count, world), flush=True)
+    total = torch.tensor([bad])
+    dist.all_reduce(total)
     dist.destroy_process_group()
+    if strict and int(total):
+        raise AssertionError('%d sharded case(s) differ from the single-GPU result' % int(total))
 
 
 if __name__ == '__main__':
