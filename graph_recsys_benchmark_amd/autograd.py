@@ -7,8 +7,12 @@ forward  = pea_model_forward_train (all P x S conv layers, softmax statistics ke
 backward = per level, last to first:
              pea_model_backward_level  -- the sparse half in HIP: relu masks, bias / attention-vector gradient
                                           reductions, gradient gathers over the reversed relations (csrc/agg_bwd.hip)
-             torch.mm on workspace views -- the dense half: dW = In^T dT, dIn = dT W (plain rocBLAS GEMMs)
-The fusion and the BPR scorer on top of `stack` are differentiated by torch autograd (models/base.py here).
+             pea_grad_weight / pea_dense_batch on workspace views -- the dense half: dW = In^T dT (row-part MFMA
+                                          reduction, fixed order), dIn = dT W (forward transform kernels); only the
+                                          first layer's dx += dT_0 W stays a torch.mm
+The fusion and the BPR scorer on top of `stack` are differentiated by torch autograd on the batch's rows only
+(models/base.py here: `_loss_autograd`), which is also what lets the last layer's gradient gathers skip every row outside
+the batch (engine.active_rows / active_ids, consumed once by the next forward / backward pair).
 """
 import ctypes as C
 
