@@ -377,6 +377,50 @@ def make_nn_convs():
     print('nn_convs.npz', {k: v.shape for k, v in out.items() if k.endswith('/out')})
 
 
+def make_graph_input_tables():
+    """A8: the reference's own update_pea_graph_input (utils/general_utils.py:280-395) on a fake dataset whose relations
+    are tiny marker arrays: which relation, flipped or not, at every (metapath, step), for each dataset branch.  The
+    module's `from ..datasets import MovieLens, Yelp` is satisfied by two placeholder names (never used by this function)."""
+    import json
+    ds_stub = types.ModuleType('graph_recsys_benchmark.datasets')
+    ds_stub.MovieLens, ds_stub.Yelp = type('MovieLens', (), {}), type('Yelp', (), {})
+    sys.modules['graph_recsys_benchmark.datasets'] = ds_stub
+    gu = importlib.import_module('graph_recsys_benchmark.utils.general_utils')
+
+    class Markers(dict):
+        """edge_index_nps: every relation asked for gets its own 2-edge marker array."""
+        def __init__(self):
+            super().__init__()
+            self.names = []
+
+        def __missing__(self, key):
+            r = len(self.names)
+            self.names.append(key)
+            self[key] = np.array([[1000 * r + 1, 1000 * r + 2], [1000 * r + 501, 1000 * r + 502]], dtype=np.float64)
+            return self[key]
+
+    out = {}
+    for tag, dargs in (('Movielens/latest-small', {'dataset': 'Movielens', 'name': 'latest-small'}),
+                       ('Movielens/25m', {'dataset': 'Movielens', 'name': '25m'}),
+                       ('Yelp', {'dataset': 'Yelp', 'name': ''})):
+        fake = types.SimpleNamespace(edge_index_nps=Markers())
+        lists = gu.update_pea_graph_input(dargs, {'device': 'cpu'}, fake)
+        table = []
+        for steps in lists:
+            row = []
+            for t in steps:
+                a = t.numpy()
+                flipped = bool(a[0, 0] % 1000 > 500)
+                r = int(a[1 if flipped else 0, 0] // 1000)
+                assert a.dtype == np.int64 and a.shape == (2, 2)
+                row.append([fake.edge_index_nps.names[r], int(flipped)])
+            table.append(row)
+        out[tag] = table
+    with open(os.path.join(OUT, 'graph_input_tables.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('graph_input_tables.json', {k: len(v) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     mods = load_reference_models()
@@ -394,3 +438,4 @@ if __name__ == '__main__':
     make_checkpoint_manifest()
     make_sampling_and_metrics(mods)
     make_nn_convs()
+    make_graph_input_tables()
