@@ -55,6 +55,16 @@ def one(rng, i):
         sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         want_loss, want = f64_loss_and_grads(kind, sd, edges, steps, heads, aggr, batch)
         assert abs(float(loss) - want_loss) <= 5e-5 * max(abs(want_loss), 1.0), 'loss %r vs %r' % (float(loss), want_loss)
+        top0 = max(float(np.abs(w).max()) for w in want.values())
+        worst = max(float(np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want[n_]).max()) /
+                    (5e-4 * max(float(np.abs(want[n_]).max()), 1e-12) + 1e-6 * top0 + 1e-8) for n_, p in model.named_parameters())
+        if os.environ.get('FUZZ_VERBOSE') and worst > 1.0:
+            print('   batch', batch[:4].tolist(), 'rows', batch.shape[0], flush=True)
+            for name, p in model.named_parameters():
+                g, w = p.grad.detach().cpu().numpy().astype(np.float64), want[name]
+                bad_rows = np.argwhere(np.abs(g - w) > 1e-4 * max(np.abs(w).max(), 1e-12))
+                print('   %-44s err %.3e scale %.3e  (%d entries off, first %s)' % (name, np.abs(g - w).max(), np.abs(w).max(),
+                                                                                 len(bad_rows), bad_rows[:4].tolist()), flush=True)
         top = max(float(np.abs(w).max()) for w in want.values())     # a gradient that is exactly 0 in float64 (e.g. d att_i when
         for name, p in model.named_parameters():                       # every logit of a row has one sign) is fp32 noise here
             g, w = p.grad.detach().cpu().numpy().astype(np.float64), want[name]
