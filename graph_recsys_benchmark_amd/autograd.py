@@ -1,7 +1,7 @@
 """loss.backward() through the HIP conv stack (reference training step solvers.py:213-216).
 
-    PEAStackFunction.apply(engine, x, *conv parameters) -> stack [N, P, R]   (the per-metapath representations that
-                                                                             models/base.py:193-196 concatenates)
+    PEAStackFunction.apply(engine, x, n_slots, options, *conv parameters) -> stack [N, P, R]
+                                      (the per-metapath representations that models/base.py:193-196 concatenates)
 
 forward  = pea_model_forward_train (all P x S conv layers, softmax statistics kept in the workspace)
 backward = per level, last to first:
@@ -12,7 +12,7 @@ backward = per level, last to first:
                                           first layer's dx += dT_0 W stays a torch.mm
 The fusion and the BPR scorer on top of `stack` are differentiated by torch autograd on the batch's rows only
 (models/base.py here: `_loss_autograd`), which is also what lets the last layer's gradient gathers skip every row outside
-the batch (engine.active_rows / active_ids, consumed once by the next forward / backward pair).
+the batch (StackOptions.read_ids).
 """
 import ctypes as C
 
@@ -186,22 +186,35 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
     return dx, grads
 
 
+class StackOptions:
+    """Per-call options of PEAStackFunction (a plain object: autograd passes it through untouched).
+    fuse_att / fuse_masked: what the by-product fused table (`fused`, set by the forward) is fused with (None: zeros).
+    read_ids: the only rows of the returned stack the caller will read (int64 ids, duplicates allowed): only they can
+    carry a gradient, so the backward moves just those rows of d_stack and (GAT) lets the last layer's gradient gathers
+    skip every other row."""
+
+    def __init__(self, fuse_att=None, fuse_masked=None, read_ids=None):
+        self.fuse_att, self.fuse_masked, self.read_ids = fuse_att, fuse_masked, read_ids
+        self.fused = None
+
+
 class PEAStackFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, engine, x, n_slots, *flat):
+    def forward(ctx, engine, x, n_slots, options, *flat):
         layer_params = [tuple(flat[i:i + n_slots]) for i in range(0, len(flat), n_slots)]
         # the fused table of the same launch is a free by-product (not differentiated here: the caller fuses the rows
-        # it needs with torch ops on the stack); engine.fuse_att / fuse_masked, when set, select what it is fused with
-        att = getattr(engine, 'fuse_att', None)
+        # it needs with torch ops on the stack)
+        options = options or StackOptions()
+        att = options.fuse_att
         if att is None:
             att = torch.zeros(engine.P, engine.repr_dim, device=x.device)
-        engine.last_fused, stack = engine.forward(layer_params, x, att=att, masked=getattr(engine, 'fuse_masked', None),
-                                                  want_stack=True, train=True)
+        options.fused, stack = engine.forward(layer_params, x, att=att, masked=options.fuse_masked, want_stack=True,
+                                              train=True)
         ctx.engine, ctx.n_slots = engine, n_slots
-        # engine.active_rows (set by the caller for ONE forward): the only rows of `stack` the loss will read, so the
-        # only rows whose gradient can be non-zero; the last layer's gradient gathers skip the others
-        ctx.active_rows, engine.active_rows = getattr(engine, 'active_rows', None), None
-        ctx.active_ids, engine.active_ids = getattr(engine, 'active_ids', None), None
+        ctx.active_ids, ctx.active_rows = options.read_ids, None
+        if options.read_ids is not None and engine.kind == 'gat':
+            ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
+            ctx.active_rows[options.read_ids] = 1
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
         ctx.present = [t is not None for t in flat]
         return stack
@@ -229,4 +242,4 @@ class PEAStackFunction(torch.autograd.Function):
         for lp, g in zip(layer_params, grads):
             for t, gt in zip(lp, g):
                 out.append(None if t is None else gt.reshape(t.shape))
-        return (None, dx, None, *out)
+        return (None, dx, None, None, *out)

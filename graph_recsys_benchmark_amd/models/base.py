@@ -14,7 +14,7 @@ import torch
 from torch.nn import Parameter
 
 from .. import engine as _engine
-from ..autograd import PEAStackFunction
+from ..autograd import PEAStackFunction, StackOptions
 from ..nn.inits import glorot
 
 
@@ -193,8 +193,7 @@ class PEABaseRecsysModel(GraphRecsysModel):
         """Differentiable forward: conv stack forward + backward in HIP, fusion (models/base.py:194-203) in torch ops."""
         eng = self._get_engine(train=True)
         flat = [t for lp in self._layer_params() for t in lp]
-        eng.fuse_att, eng.fuse_masked, eng.active_rows, eng.active_ids = None, None, None, None
-        stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
+        stack = PEAStackFunction.apply(eng, self.x, eng.slots, None, *flat)
         out = self._fuse_torch(stack, metapath_idx)
         return (out, stack) if return_stack else out
 
@@ -217,15 +216,11 @@ class PEABaseRecsysModel(GraphRecsysModel):
         (reference models/base.py:44-48).  cached_repr is the fused table of the same forward (HIP, detached)."""
         eng = self._get_engine(train=True)
         flat = [p for lp in self._layer_params() for p in lp]
-        eng.fuse_att = self.att.detach().reshape(eng.P, eng.repr_dim) if self.channel_aggr == 'att' else None
-        eng.fuse_masked = None
-        ids = t[:, :3].reshape(-1)
-        if self.kind == 'gat':                      # the stack is read at the batch's rows only: tell the backward
-            eng.active_rows = torch.zeros(self.x.shape[0], dtype=torch.uint8, device=t.device)
-            eng.active_rows[ids] = 1
-        eng.active_ids = ids                        # ... and where d_stack can be non-zero (every kind)
-        stack = PEAStackFunction.apply(eng, self.x, eng.slots, *flat)
-        self.cached_repr, self._repr_partial = eng.last_fused, False
+        ids = t[:, :3].reshape(-1)                  # the stack is read at the batch's rows only: tell the backward
+        opts = StackOptions(fuse_att=self.att.detach().reshape(eng.P, eng.repr_dim) if self.channel_aggr == 'att' else None,
+                            read_ids=ids)
+        stack = PEAStackFunction.apply(eng, self.x, eng.slots, opts, *flat)
+        self.cached_repr, self._repr_partial = opts.fused, False
         b = t.shape[0]
         rows = self._fuse_torch(stack[ids]).view(b, 3, -1)
 
