@@ -36,6 +36,7 @@ __device__ __forceinline__ void finish_row(const AggGroup &P, int row, int c4, i
     } else {
         const float inv = 1.0f / (float)(deg < 1 ? 1 : deg);
         o = scale4(sum, inv);
+        if (P.accum) o = add4(o, ld4(P.out + (size_t)row * P.ld_out + c4));  // + the root term already in the row
     }
     if (P.bias) o = add4(o, ld4(P.bias + c4));
     if (P.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));

@@ -161,6 +161,7 @@ struct AggGroup {
     float *side_out;       // D: writes the same record for its row
     float *ksum;           // D: d a_dst out / S: d a_src out, one float per head, stride ld_k
     const float *da_dst;   // S: d a_dst of the row (from the D pass), stride ld_k
+    int accum;             // AGG_MEAN: add the mean to the row already in `out` (SAGE inference schedule: root term)
     const unsigned char *row_active;  // optional [N]: 0 = the row's output gradient is exactly zero (D: row, S: gathered row)
     int ld_g, ld_side, ld_k;
 };
@@ -224,7 +225,10 @@ struct PackJob {
     int ldb;
     int in, HF, F;       // input width, output width, width per attention group
     int zero_col, zero_n;  // padding columns (relative to B) to clear in every k row
+    float *B2;           // kind PEA_PACK_SAGE2: destination of lin_root.weight^T [in][ldb2] (w0 -> B, w1 -> B2, w3 -> bias)
+    int ldb2;
 };
+constexpr int PEA_PACK_SAGE2 = 3;
 int launch_pack(const PackJob *jobs_host, int n_jobs, hipStream_t stream);
 
 // ---------------------------------------------------------------- fusion / scoring (fuse_score.hip)

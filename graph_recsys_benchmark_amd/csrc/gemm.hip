@@ -59,7 +59,7 @@ __device__ __forceinline__ void load_a(const GemmJob &J, int64_t srow, bool rv, 
         const bool ok = k < K;
         const float *p = (k < J.K1 || !ok) ? p1 + (ok ? k : 0) : p2 + (k - J.K1);
         v[q] = ld4(p);
-        bv[q] = (J.a1_mask != nullptr && k < J.K1) ? ld4(J.a1_bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[q] = (J.a1_mask != nullptr && J.a1_bias != nullptr && k < J.K1) ? ld4(J.a1_bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmBatch Bt, co
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
             const int k = 16 * i + 4 * q;
-            ab[i] = (J.a1_mask != nullptr && k < K1) ? ld4(J.a1_bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ab[i] = (J.a1_mask != nullptr && J.a1_bias != nullptr && k < K1) ? ld4(J.a1_bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // ---- weights of this job: lane (col = jr, q) holds W[16i + 4q + e][jr]
         const float *img = g_lds + Sa.lds_off[j];
@@ -571,6 +571,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackLaunch L) {
         for (int idx = tid; idx < J.in * J.HF; idx += 256) {
             const int k = idx / J.HF, o = idx % J.HF;
             J.B[(size_t)k * J.ldb + o] = J.w0[idx];
+        }
+    } else if (J.kind == PEA_PACK_SAGE2) {  // two k-major blocks: lin_rel^T (the gather source's transform), lin_root^T
+        for (int idx = tid; idx < J.HF * J.in; idx += 256) {
+            const int o = idx / J.in, k = idx % J.in;
+            J.B[(size_t)k * J.ldb + o] = J.w0[idx];
+            J.B2[(size_t)k * J.ldb2 + o] = J.w1[idx];
+        }
+        for (int idx = tid; idx < J.in * (J.ldb2 - J.HF); idx += 256) {
+            const int k = idx / (J.ldb2 - J.HF), c = idx % (J.ldb2 - J.HF);
+            J.B2[(size_t)k * J.ldb2 + J.HF + c] = 0.f;
         }
     } else {
         krows = 2 * J.in;

@@ -15,6 +15,8 @@ struct Unit {  // one channel at one level
     size_t b_off = 0;  // packed weight block (floats from the pack base)
     int ldb = 0;
     size_t bias_off = 0;
+    size_t root_off = 0;  // SAGE inference schedule: packed lin_root block [in_w][ld_root]
+    int ld_root = 0;
 };
 
 struct GroupPlan {  // one aggregation group of a level
@@ -64,6 +66,9 @@ struct pea_model {
     double alg_bytes = 0.0;
     bool single_conv = false;             // pea_*_conv: any output width, X goes to the caller's buffer
     bool backward = false;                // training buffers allocated
+    // SAGE without training buffers runs on the GAT/GCN schedule: transform first (mean_j(W x_j) = W mean_j(x_j)), so the
+    // layers gather output-width rows; the root term lin_root(x_i) + bias is written first and the mean is added to it
+    bool sage2 = false;
     const unsigned char *active_rows = nullptr;  // pea_model_set_active_rows: rows with a non-zero final-output gradient
     std::vector<int> reverse_of;          // relation -> index of the reversed relation in the plan (-1: absent)
     size_t off_dx = 0, off_gpack = 0, gpack_floats = 0, off_colsum = 0;

@@ -54,7 +54,10 @@ int build_schedule(pea_model *m) {
     const pea_plan *plan = m->plan;
     const int P = d.num_channels;
     const int64_t N = plan->N;
-    const bool sage = d.kind == PEA_KIND_SAGE, gat = d.kind == PEA_KIND_GAT;
+    // SAGE: a model with training buffers keeps the reference's order (mean of the INPUT rows, then lin_rel on the mean:
+    // the backward is written for it); without them it runs on the GAT/GCN schedule, see pea_model::sage2
+    m->sage2 = d.kind == PEA_KIND_SAGE && !m->backward;
+    const bool sage = d.kind == PEA_KIND_SAGE && !m->sage2, gat = d.kind == PEA_KIND_GAT;
     int Smax = 0;
     for (int p = 0; p < P; ++p) Smax = std::max(Smax, m->steps[(size_t)p]);
     m->levels.assign((size_t)Smax, Level());
@@ -147,6 +150,12 @@ int build_schedule(pea_model *m) {
                 pack += (size_t)K * (size_t)u.ldb;
             }
         }
+        if (m->sage2)
+            for (Unit &u : L.units) {
+                u.ld_root = pad4(u.HF);
+                u.root_off = pack;
+                pack += (size_t)u.in_w * (size_t)u.ld_root;
+            }
         if (sage) {
             for (Unit &u : L.units) {
                 u.bias_off = pack;
@@ -246,7 +255,7 @@ int build_schedule(pea_model *m) {
         for (const Unit &u : L.units) {
             const Relation &R = plan->rels[(size_t)u.rel];
             const double Nn = (double)N;
-            if (sage) {
+            if (d.kind == PEA_KIND_SAGE) {  // the yardstick counts the reference's conv calls, whatever the schedule
                 m->messages += R.e_kept;
                 m->alg_bytes += (double)R.e_kept * (4.0 * u.in_w + 4.0) + 4.0 * (Nn + 1) + 4.0 * Nn * u.in_w + 4.0 * Nn * u.HF;
             } else {
@@ -387,6 +396,11 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                     j.w3 = param(u, 1);
                     j.w1 = param(u, 2);
                     PEA_REQUIRE(j.w1 != nullptr, PEA_ERR_ARG, "forward: null lin_root.weight (channel %d step %d)", u.p, u.s);
+                    if (m->sage2) {
+                        j.kind = PEA_PACK_SAGE2;
+                        j.B2 = pack + u.root_off;
+                        j.ldb2 = u.ld_root;
+                    }
                 }
                 if (L.shared_input) {  // the last unit clears the block's padding columns
                     if (ui + 1 == L.units.size()) {
@@ -439,6 +453,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             // rows without incoming edges of a layer that feeds another layer are not aggregated at all: the next
             // transform reads T_s for them (GemmJob::a1_mask)
             const bool skip0 = mode != AGG_MEAN && !g.last && (plan->flags & PEA_PLAN_SELF_LOOPS) && !training;
+            const bool mean2 = mode == AGG_MEAN && m->sage2;  // SAGE on the GAT/GCN schedule: mean of T_s rows, added to the root term
             if (training && mode == AGG_GAT) {  // keep (max, denominator) per (row, head) for the backward
                 a.stats = wsf + L.off_stats + 2 * g.a_k;
                 a.ld_stats = L.ld_stats;
@@ -459,7 +474,22 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 a.msgs_long = (double)R.edges_long + loops * R.n_direct;
                 a.idx_share = mode == AGG_MEAN ? 1.0 : (double)g.n_convs;
             }
-            if (mode == AGG_MEAN) {
+            if (mean2) {
+                a.feat = via_slots ? wsf + g.xch_off : T + g.col;
+                a.ld_feat = via_slots ? g.xch_ld : L.ld_t;
+                a.feat_self = T + g.col;  // unused (no self loop)
+                a.ld_self = L.ld_t;
+                a.accum = 1;              // out already holds lin_root(x_i) + bias (run_gemm)
+                if (g.last) {
+                    a.out = X + g.out_col;
+                    a.ld_out = (int)ldX;
+                    a.relu = relu_last;
+                } else {
+                    a.out = O + g.out_col;
+                    a.ld_out = L.ld_o;
+                    a.relu = 1;
+                }
+            } else if (mode == AGG_MEAN) {
                 a.feat = via_slots ? wsf + g.xch_off : In + g.col;
                 a.ld_feat = via_slots ? g.xch_ld : (int)ldIn;
                 a.feat_self = In + g.col;  // unused (no self loop)
@@ -509,7 +539,33 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         const float *In;
         int64_t ldIn;
         level_io(s, T, O, In, ldIn);
-        if (kind == PEA_KIND_SAGE) {
+        // SAGE on the GAT/GCN schedule: besides T_s = In W_rel^T (the gather source, built like GCN's below) every unit
+        // gets its root term  In W_root^T + bias  written where the aggregation will add the neighbour mean
+        auto push_root_jobs = [&](std::vector<GemmJob> &jobs) {
+            if (!m->sage2) return;
+            for (const Unit &u : L.units) {
+                GemmJob J{};
+                J.A1 = In + u.in_col;
+                J.lda1 = (int)ldIn;
+                J.K1 = u.in_w;
+                J.B = pack + u.root_off;
+                J.ldb = u.ld_root;
+                J.n_out = u.ld_root;
+                J.bias = pack + u.bias_off;
+                J.n_seg = 1;
+                J.seg[0].c0 = 0;
+                J.seg[0].c1 = u.HF;
+                J.seg[0].dst = u.last ? X + u.o_col : O + u.o_col;
+                J.seg[0].ld = u.last ? (int)ldX : L.ld_o;
+                J.seg[0].relu = 0;          // relu comes after the mean has been added (finish_row)
+                if (sharded) {
+                    J.rows = own_rows;
+                    J.n_rows = n_own;
+                }
+                jobs.push_back(J);
+            }
+        };
+        if (kind == PEA_KIND_SAGE && !m->sage2) {
             std::vector<GemmJob> jobs;
             for (const Unit &u : L.units) {
                 GemmJob J{};
@@ -553,7 +609,10 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             J.seg[0].dst = T;
             J.seg[0].ld = L.ld_t;
             J.no_narrow = 1;  // same kernel family as the per-relation jobs of a sharded plan (bit-identical results)
-            return launch_gemm(J, nullptr, N, stream);
+            PEA_TRY(launch_gemm(J, nullptr, N, stream));
+            std::vector<GemmJob> roots;
+            push_root_jobs(roots);
+            return launch_gemm_batch(roots.data(), (int)roots.size(), nullptr, N, stream);
         }
         if (L.shared_input) {
             // sharded level 0: x is replicated, so each rank transforms, per relation, exactly the rows it will
@@ -593,6 +652,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 rel_jobs.push_back(J);
                 i = j;
             }
+            push_root_jobs(rel_jobs);
             PEA_TRY(launch_gemm_batch(rel_jobs.data(), (int)rel_jobs.size(), nullptr, 0, stream));
             return PEA_OK;
         }
@@ -628,6 +688,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             }
             jobs.push_back(J);
         }
+        push_root_jobs(jobs);
         return launch_gemm_batch(jobs.data(), (int)jobs.size(), own_rows, n_own, stream);
     };
 
@@ -638,12 +699,12 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
     PEA_REQUIRE(s_beg >= 0 && s_end <= n_levels, PEA_ERR_ARG, "forward: stage %d of %d", stage, n_levels);
     for (int k = s_beg; k < s_end; ++k) {
         if (k == 0) PEA_TRY(pack_weights());
-        if (kind == PEA_KIND_SAGE) {
+        if (kind == PEA_KIND_SAGE && !m->sage2) {
             PEA_TRY(run_groups(k, AGG_MEAN));
             PEA_TRY(run_gemm(k));
         } else {
             if (k == 0) PEA_TRY(run_gemm(0));
-            PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
+            PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : kind == PEA_KIND_GCN ? AGG_GCN : AGG_MEAN));
             if (k + 1 < n_levels) PEA_TRY(run_gemm(k + 1));
         }
         if (k == n_levels - 1 && (out_repr || out_stack))
@@ -741,7 +802,7 @@ extern "C" int pea_model_exchange_desc(const pea_model *model, int level, int k,
     PEA_REQUIRE(model && out && k >= 0 && k < pea_model_num_exchanges(model, level), PEA_ERR_ARG, "exchange_desc: bad argument");
     const Level &L = model->levels[(size_t)level];
     const GroupPlan &g = L.groups[(size_t)k];
-    const bool sage = model->d.kind == PEA_KIND_SAGE;
+    const bool sage = model->d.kind == PEA_KIND_SAGE && !model->sage2;  // sage2 gathers T_level like GAT/GCN
     out->relation = g.rel;
     out->slots_per_rank = model->plan->rels[(size_t)g.rel].slots_per_rank;
     out->width = g.W;
