@@ -454,11 +454,14 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             // transform reads T_s for them (GemmJob::a1_mask)
             const bool skip0 = mode != AGG_MEAN && !g.last && (plan->flags & PEA_PLAN_SELF_LOOPS) && !training;
             const bool mean2 = mode == AGG_MEAN && m->sage2;  // SAGE on the GAT/GCN schedule: mean of T_s rows, added to the root term
+            // ... whose rows without incoming edges already hold their final value up to the relu (mean = 0): they are
+            // skipped too, and the next level's transforms apply the relu when they load them (GemmJob::a1_mask)
+            const bool skip0_mean = mean2 && !g.last && !training;
             if (training && mode == AGG_GAT) {  // keep (max, denominator) per (row, head) for the backward
                 a.stats = wsf + L.off_stats + 2 * g.a_k;
                 a.ld_stats = L.ld_stats;
             }
-            if (skip0) {
+            if (skip0 || skip0_mean) {
                 a.short_rows = R.short_rows + R.n_short0;
                 a.n_short = R.n_short - R.n_short0;
             }
@@ -558,6 +561,14 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 J.seg[0].dst = u.last ? X + u.o_col : O + u.o_col;
                 J.seg[0].ld = u.last ? (int)ldX : L.ld_o;
                 J.seg[0].relu = 0;          // relu comes after the mean has been added (finish_row)
+                if (s > 0 && !training) {   // see the per-unit jobs below: edge-less rows of the previous layer, relu on load
+                    for (const Unit &up : m->levels[(size_t)s - 1].units) {
+                        if (up.p != u.p) continue;
+                        J.a1_mask = plan->rels[(size_t)up.rel].deg0;
+                        J.a1_alt = J.A1;
+                        J.lda_alt = J.lda1;
+                    }
+                }
                 if (sharded) {
                     J.rows = own_rows;
                     J.n_rows = n_own;
@@ -671,6 +682,14 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             J.seg[0].c1 = u.HF;
             J.seg[0].dst = T + u.t_col;
             J.seg[0].ld = L.ld_t;
+            if (m->sage2 && !training) {  // edge-less rows of the previous layer hold root + bias: relu on load
+                for (const Unit &up : Lp.units) {
+                    if (up.p != u.p) continue;
+                    J.a1_mask = plan->rels[(size_t)up.rel].deg0;
+                    J.a1_alt = J.A1;
+                    J.lda_alt = J.lda1;
+                }
+            }
             if ((plan->flags & PEA_PLAN_SELF_LOOPS) && !training) {  // edge-less rows of the previous layer: read T_{s-1} (see run_groups)
                 for (const Unit &up : Lp.units) {
                     if (up.p != u.p) continue;
