@@ -3,6 +3,8 @@
 //   bpr kernels   models/base.py:208-214 (predict) + models/base.py:46-48 (-sum log sigmoid(pos-neg))
 //   rank kernel   solvers.py:85-96 (score 1 + C-1 candidates, rank of the positive, auc, eval loss)
 // All reductions have a fixed order (no float atomics): results are bitwise reproducible.
+#include <mutex>
+
 #include "common.h"
 
 namespace pea {
@@ -161,7 +163,10 @@ __global__ __launch_bounds__(256) void bpr_kernel(int64_t B, int R, int64_t N, c
     if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(256) void bpr_final_kernel(int n_blocks, const float *block_sums, float *loss) {
+// An out-of-range triple contributed nothing to its block sum: the loss would be silently too small, so it is poisoned
+// with NaN instead (the reference raises at cached_repr[unids]; the host mirror raises IndexError when it next reads the
+// flag, see engine.check_pending_errors).
+__global__ __launch_bounds__(256) void bpr_final_kernel(int n_blocks, const float *block_sums, const int *err, float *loss) {
     __shared__ float red[256];
     float s = 0.f;
     for (int i = threadIdx.x; i < n_blocks; i += 256) s += block_sums[i];
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void bpr_final_kernel(int n_blocks, const floa
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = -red[0];
+    if (threadIdx.x == 0) loss[0] = err[0] ? __int_as_float(0x7fc00000) : -red[0];
 }
 
 __global__ __launch_bounds__(256) void predict_kernel(int64_t B, int R, int64_t N, const float *__restrict__ repr,
@@ -303,6 +308,19 @@ static int check_r(int R) {
     return PEA_OK;
 }
 
+// One 4-byte error flag per device, allocated on first use and kept for the life of the process (pea_predict /
+// pea_rank_eval used to hipMalloc + hipFree one per call).  The callers are the reference's single Python thread; two
+// host threads scoring at once on one device would share the flag (an error is then reported to at least one of them).
+static int *err_flag_for_current_device() {
+    static std::mutex mu;
+    static int *flags[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!flags[dev] && hipMalloc(&flags[dev], 256) != hipSuccess) flags[dev] = nullptr;
+    return flags[dev];
+}
+
 static int read_err_flag(int *err_dev, hipStream_t stream, const char *what) {
     int h = 0;
     PEA_HIP(hipMemcpyAsync(&h, err_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -331,7 +349,7 @@ extern "C" int pea_bpr_score(int64_t B, int R, int64_t num_nodes, const float *r
                            triple_stride, fc1_w, fc1_b, fc2_w, fc2_b, pos, neg, sums, err);
         PEA_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(pea::bpr_final_kernel, dim3(1), dim3(256), 0, stream, blocks, sums, loss);
+    hipLaunchKernelGGL(pea::bpr_final_kernel, dim3(1), dim3(256), 0, stream, blocks, sums, err, loss);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
@@ -343,15 +361,14 @@ extern "C" int pea_predict(int64_t B, int R, int64_t num_nodes, const float *rep
     PEA_TRY(check_r(R));
     PEA_REQUIRE(B >= 0 && repr && unids && inids && fc1_w && fc1_b && fc2_w && fc2_b && pred, PEA_ERR_ARG, "predict: bad argument");
     if (B == 0) return PEA_OK;
-    int *err = nullptr;
-    PEA_HIP(hipMalloc(&err, sizeof(int)));
+    int *err = err_flag_for_current_device();
+    PEA_REQUIRE(err != nullptr, PEA_ERR_HIP, "predict: no error-flag buffer on this device");
     PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
     const size_t sh = (size_t)(2 * R * R + 2 * R) * sizeof(float);
     hipLaunchKernelGGL(pea::predict_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), sh, stream, B, R, num_nodes,
                        repr, unids, inids, fc1_w, fc1_b, fc2_w, fc2_b, pred, err);
     int rc = hipGetLastError() == hipSuccess ? PEA_OK : PEA_ERR_HIP;
     if (rc == PEA_OK) rc = read_err_flag(err, stream, "predict");
-    (void)hipFree(err);
     return rc;
 }
 
@@ -363,15 +380,14 @@ extern "C" int pea_rank_eval(int64_t U, int C, int R, int64_t num_nodes, const f
     PEA_TRY(check_r(R));
     PEA_REQUIRE(U >= 0 && C >= 2 && repr && unids && cand && fc1_w && fc1_b && fc2_w && fc2_b, PEA_ERR_ARG, "rank_eval: bad argument");
     if (U == 0) return PEA_OK;
-    int *err = nullptr;
-    PEA_HIP(hipMalloc(&err, sizeof(int)));
+    int *err = err_flag_for_current_device();
+    PEA_REQUIRE(err != nullptr, PEA_ERR_HIP, "rank_eval: no error-flag buffer on this device");
     PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
     const size_t sh = (size_t)(2 * R * R + 2 * R) * sizeof(float);
     hipLaunchKernelGGL(pea::rank_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), sh, stream, U, C, R, num_nodes, repr,
                        unids, cand, fc1_w, fc1_b, fc2_w, fc2_b, scores, rank, auc, loss, err);
     int rc = hipGetLastError() == hipSuccess ? PEA_OK : PEA_ERR_HIP;
     if (rc == PEA_OK) rc = read_err_flag(err, stream, "rank_eval");
-    (void)hipFree(err);
     return rc;
 }
 

@@ -343,9 +343,24 @@ def dense_batch(triples_):
     _lib.check(lib.pea_dense_batch(n, len(triples_), jobs, _lib.current_stream()))
 
 
+_pending_err = []      # error flags of bpr_score calls that have not been read back yet (one int32 view each)
+
+
+def check_pending_errors():
+    """Raise IndexError if a bpr_score call since the last check saw a node id outside [0, num_nodes) -- what the
+    reference raises at `cached_repr[unids]` (models/base.py:209-210).  The flag lives on the device, so reading it is
+    a stream synchronize: it is read where the host synchronizes anyway (predict, rank_eval, model.eval(),
+    bpr_score(validate=True)); until then the loss of such a batch is NaN, never a silently smaller sum."""
+    global _pending_err
+    flags, _pending_err = _pending_err, []
+    if flags and int(torch.stack(flags).max().item()) != 0:
+        raise IndexError('index out of range in BPR triples')
+
+
 def bpr_score(repr_, triples, fc1_w, fc1_b, fc2_w, fc2_b, want_preds=False, validate=False):
     """loss = -sum(log(sigmoid(pos - neg))) over rows (u, i+, i-) of `triples` (reference models/base.py:46-48,
-    208-214).  Returns a 0-dim tensor (and pos, neg [B] when asked)."""
+    208-214).  Returns a 0-dim tensor (and pos, neg [B] when asked).  A triple with a node id out of range makes the
+    loss NaN on the device and IndexError at the next check_pending_errors() (validate=True: at once)."""
     lib = _lib.require_device()
     if triples.dtype != torch.int64 or triples.dim() != 2 or triples.shape[1] < 3:
         raise ValueError('triples must be int64 [B, >=3]')
@@ -364,14 +379,18 @@ def bpr_score(repr_, triples, fc1_w, fc1_b, fc2_w, fc2_b, want_preds=False, vali
                                  _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(args[3]), _lib.ptr(args[4]),
                                  _lib.ptr(pos), _lib.ptr(neg), _lib.ptr(loss), _lib.ptr(ws), ws_bytes,
                                  _lib.current_stream()))
-    if validate and int(ws[:4].view(torch.int32).item()) != 0:
-        raise IndexError('index out of range in BPR triples')
+    if len(_pending_err) >= 64:          # bounded: a long async loop never grows the list
+        check_pending_errors()
+    _pending_err.append(ws[:4].view(torch.int32)[0])
+    if validate:
+        check_pending_errors()
     return (loss, pos, neg) if want_preds else loss
 
 
 def predict(repr_, unids, inids, fc1_w, fc1_b, fc2_w, fc2_b):
     """fc2(relu(fc1([repr[u] || repr[i]]))) -> [B, 1]  (reference models/base.py:208-214)."""
     lib = _lib.require_device()
+    check_pending_errors()
     unids = unids.to(torch.int64).contiguous()
     inids = inids.to(torch.int64).contiguous()
     if unids.shape != inids.shape or unids.dim() != 1:
@@ -392,6 +411,7 @@ def rank_eval(repr_, unids, cand, fc1_w, fc1_b, fc2_w, fc2_b):
     """Batched evaluator (reference solvers.py:56-96): cand [U, C], column 0 = the held-out positive.
     Returns scores [U, C], rank of the positive [U] (int32), auc [U], eval loss [U]."""
     lib = _lib.require_device()
+    check_pending_errors()
     unids = unids.to(torch.int64).contiguous()
     cand = cand.to(torch.int64).contiguous()
     u, c = cand.shape

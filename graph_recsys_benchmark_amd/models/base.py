@@ -68,6 +68,7 @@ class GraphRecsysModel(torch.nn.Module):
         (models/base.py:88-96) the ablation index is honoured only by classes whose NAME starts with 'PEA'."""
         super().eval()
         self._repr_partial = False
+        _engine.check_pending_errors()       # a bad BPR batch of the epoch raises here at the latest (IndexError)
         with torch.no_grad():
             if self.__class__.__name__[:3] == 'PEA':
                 self.cached_repr = self.forward(metapath_idx)

@@ -60,8 +60,14 @@ def _workspace(plan, kind, in_channels, heads, out_channels, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
-def _ptr(p):
-    return None if p is None else C.c_void_p(p.detach().contiguous().data_ptr())
+def _ptr(p, keep):
+    """Device pointer of a parameter; a contiguous copy of a non-contiguous one (transposed / tied weight) is parked in
+    `keep`, which the caller holds until the launch has been enqueued (stream order then protects the block)."""
+    if p is None:
+        return None
+    t = p.detach().contiguous()
+    keep.append(t)
+    return C.c_void_p(t.data_ptr())
 
 
 class GATConv(torch.nn.Module):
@@ -98,9 +104,10 @@ class GATConv(torch.nn.Module):
         out = torch.empty((n, hf), dtype=torch.float32, device=x.device)
         ws, nbytes = _workspace(plan, _lib.KIND_GAT, self.in_channels, self.heads, self.out_channels, x.device)
         fused_bias = self.bias if self.concat else None
+        keep = []
         _lib.check(_lib.load().pea_gat_conv(plan._h, 0, self.in_channels, self.heads, self.out_channels,
-                                            _lib.ptr(x), x.stride(0), _ptr(self.lin.weight), _ptr(self.att_i),
-                                            _ptr(self.att_j), _ptr(fused_bias), float(self.negative_slope),
+                                            _lib.ptr(x), x.stride(0), _ptr(self.lin.weight, keep), _ptr(self.att_i, keep),
+                                            _ptr(self.att_j, keep), _ptr(fused_bias, keep), float(self.negative_slope),
                                             1 if (relu and self.concat) else 0, _lib.ptr(out), hf, _lib.ptr(ws), nbytes,
                                             _lib.current_stream()))
         if not self.concat:
@@ -146,8 +153,9 @@ class GCNConv(torch.nn.Module):
         plan = _plan_for(edge_index, n, True)
         out = torch.empty((n, self.out_channels), dtype=torch.float32, device=x.device)
         ws, nbytes = _workspace(plan, _lib.KIND_GCN, self.in_channels, 1, self.out_channels, x.device)
+        keep = []
         _lib.check(_lib.load().pea_gcn_conv(plan._h, 0, self.in_channels, self.out_channels, _lib.ptr(x), x.stride(0),
-                                            _ptr(self.weight), _ptr(self.bias), 1 if self.gcn_deg_from == 'col' else 0,
+                                            _ptr(self.weight, keep), _ptr(self.bias, keep), 1 if self.gcn_deg_from == 'col' else 0,
                                             1 if relu else 0, _lib.ptr(out), self.out_channels, _lib.ptr(ws), nbytes,
                                             _lib.current_stream()))
         return out
@@ -178,9 +186,10 @@ class SAGEConv(torch.nn.Module):
         plan = _plan_for(edge_index, n, False)
         out = torch.empty((n, self.out_channels), dtype=torch.float32, device=x.device)
         ws, nbytes = _workspace(plan, _lib.KIND_SAGE, self.in_channels, 1, self.out_channels, x.device)
+        keep = []
         _lib.check(_lib.load().pea_sage_conv(plan._h, 0, self.in_channels, self.out_channels, _lib.ptr(x), x.stride(0),
-                                             _ptr(self.lin_rel.weight), _ptr(self.lin_rel.bias),
-                                             _ptr(self.lin_root.weight), 1 if relu else 0, _lib.ptr(out),
+                                             _ptr(self.lin_rel.weight, keep), _ptr(self.lin_rel.bias, keep),
+                                             _ptr(self.lin_root.weight, keep), 1 if relu else 0, _lib.ptr(out),
                                              self.out_channels, _lib.ptr(ws), nbytes, _lib.current_stream()))
         return out
 

@@ -166,7 +166,20 @@ class NGCFConv(torch.nn.Module):
         glorot(self.W_1)
         glorot(self.W_2)
 
+    def _without_self_loops(self, edge_index):
+        """remove_self_loops(edge_index), as the reference does before counting degrees and propagating
+        (nn/ngcf_conv.py:33-34).  The filtered tensor is cached per input tensor so the plan cache keeps hitting."""
+        key = (id(edge_index), edge_index._version)
+        hit = getattr(self, '_noloop', None)
+        if hit is not None and hit[0] == key and hit[1]() is edge_index:
+            return hit[2]
+        keep = edge_index[0] != edge_index[1]
+        filtered = edge_index if bool(keep.all()) else edge_index[:, keep].contiguous()
+        self._noloop = (key, weakref.ref(edge_index), filtered)
+        return filtered
+
     def forward(self, x, edge_index, size=None):
+        edge_index = self._without_self_loops(edge_index)
         if not hasattr(self, 'deg'):     # cached on first use like the reference (which counts in an O(N*E) loop)
             cnt = torch.bincount(edge_index.reshape(-1), minlength=x.shape[0])
             self.deg = (cnt // 2 if self.deg_div == 'floor' else cnt / 2).view(-1, 1)

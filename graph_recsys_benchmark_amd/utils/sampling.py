@@ -4,6 +4,7 @@ seeds (`random.seed / np.random.seed / torch.manual_seed`, reference solvers.py:
     cf_negative_sampling   graph_recsys_benchmark/datasets/movielens.py:879-997 (BPR branch :920-940, shuffle :994-997)
                            (Yelp twin: datasets/yelp.py:746-760)
     generate_candidates    graph_recsys_benchmark/solvers.py:21-31
+    entity_aware_row       graph_recsys_benchmark/datasets/movielens.py:1147-1181 (the six entity columns of a row)
 
 They stay on the host on purpose: numpy's legacy RandomState stream and Python's `random` are version-frozen, a
 device-side Philox stream would not reproduce the reference's ids.
@@ -40,11 +41,42 @@ def cf_negative_sampling(dataset):
     else:
         raise NotImplementedError
     train_data_np = np.hstack([train_data_np, neg])
+    if getattr(dataset, 'entity_aware', False) and not hasattr(dataset, 'iid_feat_nids'):
+        # the reference builds the per-item / per-user entity lists here from its processed CSV files
+        # (datasets/movielens.py:941-991): dataset ETL, outside the accelerated path.  Without them the six
+        # entity columns __getitem__ appends (see entity_aware_row) cannot be drawn, and a model with
+        # entity_aware=True would index columns 3..8 of a 3-column batch.
+        raise NotImplementedError('entity_aware=True needs dataset.iid_feat_nids / uid_feat_nids / nid2e_dict '
+                                  '(built by the reference\'s dataset preprocessing); attach them to the dataset')
     train_data_t = torch.from_numpy(train_data_np).long()
     shuffle_idx = torch.randperm(train_data_t.shape[0])
     dataset.train_data = train_data_t[shuffle_idx]
     dataset.train_data_length = train_data_t.shape[0]
     return dataset.train_data
+
+
+def entity_aware_row(dataset, train_data_t):
+    """One training row as the reference's Dataset.__getitem__ returns it (datasets/movielens.py:1147-1181): with
+    dataset.entity_aware the (u, i+, i-) row gets six more columns -- positive / negative entity of the item, mask,
+    positive / negative entity of the user, mask -- drawn with Python's `random` in the reference's call order (bit-exact
+    when called from the seeded main process; the reference's DataLoader workers make its own stream irreproducible,
+    SURVEY.md appendix C.10).  `train_data_t`: int64 [3] tensor = dataset.train_data[idx]."""
+    if not getattr(dataset, 'entity_aware', False):
+        return train_data_t
+    out = []
+    for col, feats_of, acc in ((1, dataset.iid_feat_nids, dataset.type_accs['iid']),
+                               (0, dataset.uid_feat_nids, dataset.type_accs['uid'])):
+        nid = int(train_data_t[col])
+        feat_nids = feats_of[int(nid - acc)]
+        if len(feat_nids) == 0:
+            out += [0, 0, 0]
+        else:
+            pos_entity = rd.choice(feat_nids)
+            entity_type = dataset.nid2e_dict[pos_entity][0]
+            lower = dataset.type_accs.get(entity_type)
+            upper = lower + getattr(dataset, 'num_' + entity_type + 's')
+            out += [pos_entity, rd.choice(range(lower, upper)), 1]
+    return torch.cat([train_data_t, torch.tensor(out, dtype=torch.long)], dim=-1)
 
 
 def generate_candidates(dataset, u_nid, num_neg_candidates=99):
@@ -79,6 +111,14 @@ def device_negative_sampling(dataset, seed, epoch=0, device='cuda', shuffle=True
                                         0 if keys is None else keys.numel(), int(seed) & (2 ** 64 - 1),
                                         int(epoch) & 0xFFFFFFFF, _lib.ptr(out), out.stride(0), _lib.ptr(exhausted),
                                         _lib.current_stream()))
+    n_exhausted = int(exhausted.item())
+    if n_exhausted:
+        # 'unseen': 64 rejection attempts all hit seen items (a user who has rated nearly every item); the row keeps
+        # a seen item as its negative.  Loud, because such a row is a false negative.
+        import warnings
+        warnings.warn('device_negative_sampling: %d of %d negatives are seen items (rejection sampling exhausted)'
+                      % (n_exhausted, out.shape[0]), RuntimeWarning)
+    dataset.negatives_exhausted = n_exhausted
     if shuffle:
         out = out[torch.randperm(out.shape[0], device=device)]
     dataset.train_data, dataset.train_data_length = out, out.shape[0]

@@ -338,6 +338,38 @@ def make_sampling_and_metrics(mods):
           'HR@10 %.4f' % hr[5])
 
 
+def entity_fake_dataset(seed=13):
+    """_FakeDataset + the entity lists the reference builds from its CSV files (datasets/movielens.py:941-991):
+    per item / per user a list of entity node ids (some empty), nid -> (type, entity) and per-type id blocks."""
+    fake = _FakeDataset(seed)
+    rng = np.random.default_rng(seed + 100)
+    base = fake.num_uids + fake.num_iids
+    fake.type_accs.update({'genre': base, 'tid': base + 5})
+    fake.num_genres, fake.num_tids = 5, 9
+    fake.nid2e_dict = {base + k: ('genre', k) for k in range(5)}
+    fake.nid2e_dict.update({base + 5 + k: ('tid', k) for k in range(9)})
+    fake.iid_feat_nids = [[int(base + v) for v in rng.integers(0, 14, size=int(rng.integers(0, 4)))]
+                          for _ in range(fake.num_iids)]
+    fake.uid_feat_nids = [[int(base + 5 + v) for v in rng.integers(0, 9, size=int(rng.integers(0, 3)))]
+                          for _ in range(fake.num_uids)]
+    fake.entity_aware = True
+    return fake
+
+
+def make_entity_rows(mods):
+    """The six entity columns of a training row: the reference's own Dataset.__getitem__
+    (datasets/movielens.py:1147-1181) on a fake dataset, main process, seeded `random`."""
+    ml, _ = load_reference_sampling_and_solver(mods)
+    fake = entity_fake_dataset()
+    fake.sampling_strategy = 'random'
+    random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
+    ml.MovieLens.cf_negative_sampling(fake)           # entity lists already attached: the CSV branch is skipped
+    random.seed(77)
+    rows = torch.stack([ml.MovieLens.__getitem__(fake, i) for i in range(200)])
+    np.savez_compressed(os.path.join(OUT, 'entity_rows.npz'), rows=rows.numpy(), train_data=fake.train_data.numpy())
+    print('entity_rows.npz', tuple(rows.shape), 'masked rows', int((rows[:, 5] == 0).sum()), int((rows[:, 8] == 0).sum()))
+
+
 def make_nn_convs():
     """The reference's OWN conv classes (graph_recsys_benchmark/nn/{kgat,kgcn,ngcf}_conv.py) run for real; the only
     foreign pieces are the MessagePassing base / remove_self_loops (restated, oracle/pyg_restatement.py)."""
@@ -373,6 +405,16 @@ def make_nn_convs():
             out[name + '/out'] = m(*args).numpy()
         for pn, p_ in m.named_parameters():
             out[name + '/param/' + pn] = p_.detach().numpy()
+    # NGCF only: an edge list WITH self loops -- the reference strips them (nn/ngcf_conv.py:33-34) before it counts
+    # degrees and propagates (KGAT / KGCN cannot take such input: att_map would no longer line up with the edges)
+    loops = np.stack([np.arange(0, n, 7), np.arange(0, n, 7)]).astype(np.int64)
+    ei_loop = np.concatenate([ei[:, :700], loops, ei[:, 700:]], axis=1)
+    out['ngcf_selfloop/edge_index'] = ei_loop
+    m = ngcf(32, 16)
+    with torch.no_grad():
+        out['ngcf_selfloop/out'] = m(xt, torch.from_numpy(ei_loop)).numpy()
+    for pn, p_ in m.named_parameters():
+        out['ngcf_selfloop/param/' + pn] = p_.detach().numpy()
     np.savez_compressed(os.path.join(OUT, 'nn_convs.npz'), **out)
     print('nn_convs.npz', {k: v.shape for k, v in out.items() if k.endswith('/out')})
 
@@ -437,5 +479,6 @@ if __name__ == '__main__':
     make_rng_streams()
     make_checkpoint_manifest()
     make_sampling_and_metrics(mods)
+    make_entity_rows(mods)
     make_nn_convs()
     make_graph_input_tables()

@@ -149,14 +149,22 @@ def f64_forward(kind, sd, edges, steps, heads, channel_aggr, gcn_deg_from='row')
 
 
 def assert_fp32_close(got, want, truth, rtol=1e-5, atol=1e-6, what=''):
-    """Passes when `got` is elementwise within rtol/atol of `want`, OR its error against the float64 `truth`
-    is no larger than 2x the fp32 oracle's own error plus atol (different, equally valid summation orders)."""
+    """Passes when `got` is elementwise within rtol/atol of `want`; an element that misses that bound must sit in a
+    ROW (one destination node's output vector, per channel for a [N, P, R] stack) whose error against the float64 `truth` is no larger than 2x the fp32
+    oracle's own error IN THAT SAME ROW plus atol (two valid fp32 summation orders of the same hub row).  The
+    fallback is per row: a bad element cannot hide behind the oracle's worst row elsewhere in the array."""
     got, want, truth = np.asarray(got, np.float64), np.asarray(want, np.float64), np.asarray(truth, np.float64)
     bad = np.abs(got - want) > atol + rtol * np.abs(want)
     if not bad.any():
         return
-    e_got = np.abs(got - truth).max()
-    e_orc = np.abs(want - truth).max()
-    scale = np.abs(truth).max()
-    assert e_got <= 2.0 * e_orc + atol + 2e-7 * scale, \
-        '%s: %d elements off; max err vs f64: hip %.3e, fp32 oracle %.3e (scale %.3e)' % (what, bad.sum(), e_got, e_orc, scale)
+    width = got.shape[-1] if got.ndim > 1 else got.size      # one row = one output vector of one node (and channel)
+    g2, w2, t2, b2 = (a.reshape(-1, width) for a in (got, want, truth, bad))
+    bad_rows = np.flatnonzero(b2.any(axis=1))
+    e_got = np.abs(g2[bad_rows] - t2[bad_rows]).max(axis=1)
+    e_orc = np.abs(w2[bad_rows] - t2[bad_rows]).max(axis=1)
+    scale = np.abs(t2[bad_rows]).max(axis=1)
+    ok = e_got <= 2.0 * e_orc + atol + 2e-7 * scale
+    if not ok.all():
+        k = int(np.flatnonzero(~ok)[0])
+        raise AssertionError('%s: %d elements in %d rows off; row %d: err vs f64 hip %.3e, fp32 oracle %.3e (row scale %.3e)'
+                             % (what, int(bad.sum()), bad_rows.size, int(bad_rows[k]), e_got[k], e_orc[k], scale[k]))

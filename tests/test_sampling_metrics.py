@@ -51,6 +51,49 @@ def test_negative_sampling_is_bit_exact(strategy):
     assert got.dtype == np.int64 and ds.train_data_length == got.shape[0]
 
 
+def _entity_dataset(seed=13):
+    """Same construction as oracle/make_golden.py::entity_fake_dataset."""
+    fake = FakeDataset(seed)
+    rng = np.random.default_rng(seed + 100)
+    base = fake.num_uids + fake.num_iids
+    fake.type_accs.update({'genre': base, 'tid': base + 5})
+    fake.num_genres, fake.num_tids = 5, 9
+    fake.nid2e_dict = {base + k: ('genre', k) for k in range(5)}
+    fake.nid2e_dict.update({base + 5 + k: ('tid', k) for k in range(9)})
+    fake.iid_feat_nids = [[int(base + v) for v in rng.integers(0, 14, size=int(rng.integers(0, 4)))]
+                          for _ in range(fake.num_iids)]
+    fake.uid_feat_nids = [[int(base + 5 + v) for v in rng.integers(0, 9, size=int(rng.integers(0, 3)))]
+                          for _ in range(fake.num_uids)]
+    fake.entity_aware = True
+    return fake
+
+
+def test_entity_aware_rows_are_bit_exact():
+    """The six entity columns against rows produced by the reference's own Dataset.__getitem__
+    (datasets/movielens.py:1147-1181; oracle/make_golden.py::make_entity_rows)."""
+    from graph_recsys_benchmark_amd.utils import cf_negative_sampling, entity_aware_row
+    z = np.load(os.path.join(GOLDEN, 'entity_rows.npz'))
+    ds = _entity_dataset()
+    ds.sampling_strategy = 'random'
+    random.seed(2020)
+    np.random.seed(2020)
+    torch.manual_seed(2020)
+    cf_negative_sampling(ds)
+    np.testing.assert_array_equal(ds.train_data.numpy(), z['train_data'])
+    random.seed(77)
+    rows = torch.stack([entity_aware_row(ds, ds.train_data[i]) for i in range(200)]).numpy()
+    np.testing.assert_array_equal(rows, z['rows'])
+    assert rows.shape == (200, 9) and (rows[:, 5] == 0).any() and (rows[:, 8] == 1).any()
+
+
+def test_entity_aware_sampling_without_entity_lists_raises():
+    from graph_recsys_benchmark_amd.utils import cf_negative_sampling
+    ds = FakeDataset(11)
+    ds.sampling_strategy, ds.entity_aware = 'random', True
+    with pytest.raises(NotImplementedError):
+        cf_negative_sampling(ds)
+
+
 def test_rank_metrics_match_rec_utils_definitions():
     from graph_recsys_benchmark_amd.solvers import metrics_from_ranks
     with open(os.path.join(GOLDEN, 'rec_utils.json')) as f:
