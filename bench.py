@@ -9,16 +9,27 @@ resident in HBM when the timed region starts.  value = messages reduced per step
 E + N self loops) / step time, whole job.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--preset ml25m_shaped] [--kind gat]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (N > 1, one rank per GPU)
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream over the timed
-region (pea_profile_*); `cpu_baseline` times the CPU oracle (oracle/pea_oracle.c, a port of the reference's
-PyG op sequence) on a bounded sample of the same workload.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (one process per GPU,
+127.0.0.1 rendezvous) BEFORE anything touches a GPU; under an external launcher (torch.distributed.run) it is one
+of the ranks.  Rank 0 prints ONE JSON line.
+
+`roofline` (dominant kernel, measured live with HIP events on the launch stream, pea_profile_*):
+    achieved = bytes the launch pulls through the memory system (row chunk + source index of every message, once)
+               / its average duration
+    peak     = the gather ceiling of the cache tier those rows are served from (MI355X_MICROARCH.md, "Indexed rows":
+               L2 18.8 TB/s, Infinity Cache 8.6 TB/s, HBM 6.1 TB/s), tier named from the measured L2 hit rate of THIS
+               preset / kind (profiles/traffic.json) or, without one, from the table's footprint
+    traffic  = fabric-side bytes per launch from the rocprofv3 PMC passes of this preset / kind (or null)
+    algorithmic = the SURVEY.md 8(d) yardstick (what the reference's separate conv calls would move), for reference
+`hbm_floor`: compulsory HBM bytes of the step / 8 TB/s against the measured step time.
+`cpu_baseline`: the CPU oracle (oracle/pea_oracle.c, a port of the reference's PyG op sequence) on the same step.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,13 +39,14 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from graph_recsys_benchmark_amd import _lib, models  # noqa: E402
-from graph_recsys_benchmark_amd.utils import SyntheticHIN, update_pea_graph_input  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+# measured gather ceilings by where the rows are served from (MI355X_MICROARCH.md, section "Indexed rows: gather into
+# LDS": 16.8-18.8 TB/s L2-resident, 8.6 TB/s from a 38 MB table in the Infinity Cache, 6.0-6.1 TB/s from HBM)
+GATHER_CEILING_GBS = {'l2': 18800.0, 'infinity_cache': 8600.0, 'hbm': 6100.0}
+L2_BYTES, MALL_BYTES = 32 << 20, 256 << 20   # aggregate L2 (8 x 4 MiB), Infinity Cache
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -42,8 +54,11 @@ def parse():
     ap.add_argument('--preset', default='ml25m_shaped')
     ap.add_argument('--kind', default='gat', choices=['gat', 'gcn', 'sage'])
     ap.add_argument('--scale', type=float, default=1.0, help='edge/node count multiplier (tests only)')
+    ap.add_argument('--metapaths', type=int, default=0, help='use the first n metapaths of the dataset table (0 = the preset\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-samples', type=int, default=3, help='timed runs of the CPU oracle (median reported)')
     ap.add_argument('--no-profile', action='store_true', help='skip the HIP-event roofline leg')
+    ap.add_argument('--no-extras', action='store_true', help='skip the eval-variant and 13-metapath legs')
     ap.add_argument('--graph', action='store_true', help='N=1 only: replay the forward from a captured hipGraph\n'
                     '(PEAEngine.forward_graphed; for launch-bound presets such as ml_small)')
     ap.add_argument('--train-steps', type=int, default=0, help='also time this many full training steps '
@@ -52,10 +67,35 @@ def parse():
                     'this many ranks with the collectives skipped (results are wrong, timings are per-rank compute + host work)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' "
                     'only to rehearse several ranks on one GPU)')
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 without an external launcher: start N fresh ranks of this script (nothing in this process has
+    touched a GPU: only argparse and imports ran) and relay rank 0's JSON line.  Returns the exit code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:           # a rank that died takes the job down: no orphans holding a GPU
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def build_model(dataset, kind, device):
+    from graph_recsys_benchmark_amd import models
+    from graph_recsys_benchmark_amd.utils import update_pea_graph_input
     base = {'gat': models.PEAGATRecsysModel, 'gcn': models.PEAGCNRecsysModel, 'sage': models.PEASageRecsysModel}[kind]
     dataset_args = dataset.dataset_args()
     train_args = {'device': device, 'num_metapaths': dataset.spec['num_metapaths']}
@@ -75,38 +115,39 @@ def build_model(dataset, kind, device):
 
 
 def read_profile():
+    """{kernel name: [launches, ms, algorithmic bytes, gathered bytes, largest gather table bytes]} since the last read."""
+    import ctypes as C
+    from graph_recsys_benchmark_amd import _lib
     lib = _lib.load()
     cap = 1 << 16
     names = C.create_string_buffer(cap * 32)
     ms = (C.c_float * cap)()
-    units = (C.c_double * cap)()
+    units, pulled, table = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
     cnt = C.c_int()
-    lib.pea_profile_read(cap, names, ms, units, C.byref(cnt))
+    lib.pea_profile_read_ex(cap, names, ms, units, pulled, table, C.byref(cnt))
     out = {}
     for i in range(cnt.value):
         nm = names.raw[i * 32:(i + 1) * 32].split(b'\0')[0].decode()
-        rec = out.setdefault(nm, [0, 0.0, 0.0])
+        rec = out.setdefault(nm, [0, 0.0, 0.0, 0.0, 0.0])
         rec[0] += 1
         rec[1] += ms[i]
         rec[2] += units[i]
+        rec[3] += pulled[i]
+        rec[4] = max(rec[4], table[i])
     return out
 
 
-def cpu_baseline(dataset, model, kind):
-    """The CPU oracle (oracle/pea_oracle.c: the reference's PyG op sequence in C, OpenMP on the loops torch runs in
-    parallel) on the SAME workload: every metapath channel of the same graph, then the fusion."""
+def oracle_channels(dataset, model, kind, channels):
+    """Per-channel [N, R] outputs of the CPU oracle for the listed channel indices (+ messages reduced)."""
     from oracle import oracle as orc
     from graph_recsys_benchmark_amd.utils import metapath_table
-    table = metapath_table(dataset.dataset_args())[:dataset.spec['num_metapaths']]
+    table = metapath_table(dataset.dataset_args())
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     n = dataset.num_nodes
-    cores = min(len(os.sched_getaffinity(0)), 64)
-    orc.set_num_threads(cores)
     cache, outs, msgs = {}, [], 0
-    t0 = time.perf_counter()
-    for p, steps in enumerate(table):
+    for p in channels:
         edges = []
-        for rel, flipped in steps:
+        for rel, flipped in table[p]:
             if (rel, flipped) not in cache:
                 e = dataset.edge_index_nps[rel].astype(np.int64)
                 cache[(rel, flipped)] = np.ascontiguousarray(e[::-1]) if flipped else e
@@ -115,21 +156,69 @@ def cpu_baseline(dataset, model, kind):
                 if k.startswith('pea_channels.%d.gnn_layers.%d.' % (p, s))} for s in range(len(edges))]
         outs.append(orc.channel_forward(kind, sd['x'], edges, lps, [1] * len(edges)))
         msgs += sum(e.shape[1] + (n if kind != 'sage' else 0) for e in edges)
-    fused = orc.fuse(np.stack(outs, axis=1), sd.get('att'))
-    dt = time.perf_counter() - t0
-    return dict(value=msgs / dt, unit='edges/s', cores=cores, kind='port',
-                sample='one full step on the CPU: all %d metapath channels x 2 layers + fusion, %d messages, %.1f s '
-                       '(edge-list int64 copies included)' % (len(table), msgs, dt)), fused
+    return outs, msgs, sd
+
+
+def cpu_baseline(dataset, model, kind, samples):
+    """The CPU oracle (oracle/pea_oracle.c: the reference's PyG op sequence in C, OpenMP on the loops torch runs in
+    parallel) on the SAME workload: every metapath channel of the same graph, then the fusion.  Median of `samples`
+    timed runs after none (the first run pages the inputs in and is part of the sample: the CPU path has no warm-up
+    to speak of at 12 s per step)."""
+    from oracle import oracle as orc
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    orc.set_num_threads(cores)
+    p_all = list(range(dataset.spec['num_metapaths']))
+    times, fused, msgs = [], None, 0
+    for _ in range(max(1, samples)):
+        t0 = time.perf_counter()
+        outs, msgs, sd = oracle_channels(dataset, model, kind, p_all)
+        fused = orc.fuse(np.stack(outs, axis=1), sd.get('att'))
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    return dict(value=msgs / dt, unit='edges/s', cores=cores, kind='port', samples=len(times),
+                seconds=[round(t, 2) for t in times],
+                sample='one full step on the CPU per sample: all %d metapath channels x 2 layers + fusion, %d messages, '
+                       'median of %d runs = %.1f s (edge-list int64 copies included; BPR scoring of the batch, '
+                       'microseconds, excluded)' % (len(p_all), msgs, len(times), dt)), fused
+
+
+def load_traffic(preset, kind, scale, world):
+    """{kernel: {hbm_bytes_per_launch, l2_hit_rate, ...}} measured with rocprofv3 PMC passes for THIS preset / kind at
+    full scale on one GPU (profiles/traffic.json, written by profiles/summarize.py), or {}."""
+    if scale != 1.0 or world != 1:
+        return {}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            return json.load(f).get('%s/%s' % (preset, kind), {})
+    except Exception:
+        return {}
+
+
+def gather_tier(table_bytes, l2_hit_rate):
+    """Which cache tier serves the gathered rows: from the measured L2 hit rate when there is one (>= 0.5: the XCD L2s),
+    else from the table's footprint against the aggregate L2 / the Infinity Cache."""
+    if l2_hit_rate is not None:
+        if l2_hit_rate >= 0.5:
+            return 'l2', 'measured L2 hit rate %.2f' % l2_hit_rate
+        return ('infinity_cache' if table_bytes <= MALL_BYTES else 'hbm'), 'measured L2 hit rate %.2f, table %.0f MB' % (l2_hit_rate, table_bytes / 1e6)
+    if table_bytes <= L2_BYTES // 8:
+        return 'l2', 'table %.1f MB fits one XCD L2 (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
+    if table_bytes <= MALL_BYTES:
+        return 'infinity_cache', 'table %.0f MB fits the Infinity Cache (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
+    return 'hbm', 'table %.0f MB exceeds the Infinity Cache' % (table_bytes / 1e6)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    from graph_recsys_benchmark_amd import _lib
+    from graph_recsys_benchmark_amd.utils import SyntheticHIN
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -142,9 +231,12 @@ def main():
     _lib.require_device()
 
     dataset = SyntheticHIN(args.preset, seed=2019, scale=args.scale)
+    if args.metapaths:
+        dataset.spec = dict(dataset.spec, num_metapaths=args.metapaths)
     model = build_model(dataset, args.kind, device)
     model.train()
-    batch = torch.from_numpy(dataset.bpr_batch()).to(device)
+    batch_host = dataset.bpr_batch()
+    batch = torch.from_numpy(batch_host).to(device)
     if world > 1:
         model.shard(rank, world)     # destination rows tile-interleaved over the ranks; exchanges over RCCL
     elif args.emulate_world > 1:
@@ -181,15 +273,15 @@ def main():
     lib = _lib.load()
     profile = not args.no_profile
 
-    def timed_region(with_events):
+    def timed_region(fn, steps, with_events=False):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         lib.pea_profile_enable(1 if with_events else 0)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        for _ in range(steps):
+            out = fn()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -197,20 +289,20 @@ def main():
         elapsed = time.perf_counter() - t0
         lib.pea_profile_enable(0)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, out
 
     # the timed region proper (K steps, nothing but the work), then the same K steps again with a pair of HIP events
     # around every kernel launch (on the launch stream) for the per-kernel roofline
-    dt, loss = timed_region(False)
+    dt, loss = timed_region(step, args.steps)
     prof, dt_prof = {}, None
     comm_ms = None
     if profile:
         from graph_recsys_benchmark_amd.sharding import CommTimer
         CommTimer.enabled, CommTimer.events = world > 1, []
-        dt_prof, loss = timed_region(True)
+        dt_prof, loss = timed_region(step, args.steps, True)
         prof = read_profile()
         if world > 1:                      # device time between the start and the end of every collective, this rank
             comm_ms = CommTimer.total_ms() / args.steps
@@ -218,10 +310,13 @@ def main():
 
     eng = model._engine
     messages = eng.messages
-    ms_per_step = dt / args.steps * 1e3
-    value = messages / (dt / args.steps)
+    step_s = dt / args.steps
+    ms_per_step = step_s * 1e3
+    value = messages / step_s
     b = batch.shape[0]
     alg_bytes = eng.algorithmic_bytes + b * (12 + 12 * dataset.spec['repr_dim'] + 4)
+    floor_bytes = eng.compulsory_bytes
+    floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 / world
 
     out = {
         'metric': 'BPR-scored edges/sec, PEAGAT MovieLens-25m, emb_dim=64, 9 metapaths',
@@ -233,30 +328,49 @@ def main():
                                % (args.preset, args.kind.upper(), dataset.num_nodes, dataset.spec['num_metapaths'],
                                   messages, dataset.spec['emb_dim'], dataset.spec['hidden_size'],
                                   dataset.spec['repr_dim'], b),
-                   'parallelism': 'rows%d' % world if world > 1 else 'single', 'loss': float(loss)},
-        'bpr_triples_per_s': b / (dt / args.steps),
+                   'parallelism': 'rows%d' % world if world > 1 else 'single', 'loss': float(loss),
+                   'batch_h2d': 'excluded: the %d-byte batch is resident in HBM when the timed region starts (bench '
+                                'contract); over PCIe it is a ~10 us copy' % batch_host.nbytes},
+        'bpr_triples_per_s': b / step_s,
         'ms_per_step_with_kernel_events': None if dt_prof is None else dt_prof / args.steps * 1e3,
         'exchange_ms_per_step': comm_ms,   # N > 1: stream time inside the collectives (rank 0), from the profiled pass
-        'forward_roofline': {'algorithmic_bytes_per_step': alg_bytes,
-                             'achieved_GBs': alg_bytes / (dt / args.steps) / 1e9,
-                             'frac_of_8TBs': alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world},
+        # whole step against DRAM: every buffer of the schedule written once + read once, indices once, at 8 TB/s
+        'hbm_floor': {'compulsory_bytes_per_step': floor_bytes, 'floor_ms_at_8TBs': floor_ms,
+                      'frac': floor_ms / ms_per_step,
+                      'note': 'step time is dominated by gathers served from L2 / Infinity Cache (roofline below), not by DRAM'},
+        # the SURVEY.md 8(d) yardstick: bytes the REFERENCE's op sequence would move (per conv call its own index read,
+        # [N, F] writes ...).  The schedule reads indices once per relation and keeps tables cache resident, so this
+        # rate is NOT DRAM traffic and may exceed 8 TB/s: reported for comparison with BASELINE.md only.
+        'reference_yardstick': {'algorithmic_bytes_per_step': alg_bytes, 'GBs': alg_bytes / step_s / 1e9},
     }
     if prof:
+        traffic_tab = load_traffic(args.preset, args.kind, args.scale, world if not args.emulate_world else args.emulate_world)
         dom = max(prof.items(), key=lambda kv: kv[1][1])
-        name, (launches, ms, units) = dom
-        achieved = units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = load_traffic(name)
-        out['roofline'] = {'bound': 'hbm', 'kernel': name, 'launches': launches,
-                           'avg_launch_ms': ms / launches, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                           'algorithmic_bytes_per_launch': units / launches,
-                           # the committed PMC traffic of this kernel over its live duration: what the fabric really moved
-                           # (algorithmic bytes count the reference's per-channel re-reads, so `frac` can exceed 1)
-                           'traffic_GBs': None if not traffic or world > 1 else traffic / (ms / launches * 1e-3) / 1e9,
-                           'traffic_frac': None if not traffic or world > 1 else traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        name, (launches, ms, units, pulled, table) = dom
+        avg_s = ms / launches * 1e-3
+        meas = traffic_tab.get(name, {})
+        hit = meas.get('l2_hit_rate')
+        tier, why = gather_tier(table, hit)
+        peak = GATHER_CEILING_GBS[tier] if pulled > 0 else HBM_PEAK_GBS
+        achieved = (pulled if pulled > 0 else units) / launches / avg_s / 1e9
+        traffic = meas.get('hbm_bytes_per_launch')
+        out['roofline'] = {
+            'bound': 'hbm', 'kernel': name, 'launches': launches, 'avg_launch_ms': ms / launches,
+            'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
+            'tier': tier, 'tier_from': why, 'gather_table_bytes': table,
+            'gathered_bytes_per_launch': pulled / launches,
+            'traffic': traffic,          # fabric-side bytes per launch (rocprofv3 PMC, this preset / kind) or null
+            'traffic_GBs': None if not traffic else traffic / avg_s / 1e9,
+            'traffic_frac_of_8TBs': None if not traffic else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
+            'l2_hit_rate': hit,
+            'algorithmic_bytes_per_launch': units / launches,      # SURVEY.md 8(d) yardstick share of this launch
+            'algorithmic_GBs': units / launches / avg_s / 1e9,
+            'definition': 'achieved = (4*W row bytes + 4 index bytes) x messages of the launch / avg launch time; peak = '
+                          'measured row-gather ceiling of the named cache tier (MI355X_MICROARCH.md, Indexed rows)'}
         out['kernels_ms_per_step'] = {k: round(v[1] / args.steps, 4) for k, v in
                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}
-    if world == 1 and args.train_steps > 0:
+    single = world == 1 and args.emulate_world <= 1
+    if single and args.train_steps > 0:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
 
         def train_step():
@@ -268,12 +382,8 @@ def main():
 
         for _ in range(2):
             train_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.train_steps):
-            l = train_step()
-        torch.cuda.synchronize()
-        tt = (time.perf_counter() - t0) / args.train_steps
+        tt, l = timed_region(train_step, args.train_steps)
+        tt /= args.train_steps
         out['training_step'] = {'ms_per_step': tt * 1e3, 'steps': args.train_steps, 'loss': float(l),
                                 'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step'}
         if profile:
@@ -283,27 +393,92 @@ def main():
             lib.pea_profile_enable(0)
             out['training_step']['hip_kernels_ms'] = {k: round(v[1], 3) for k, v in
                                                       sorted(read_profile().items(), key=lambda kv: -kv[1][1])}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, want = cpu_baseline(dataset, model, args.kind)
+    if single and not args.no_extras:
+        out['eval_variant'] = eval_variant(dataset, model, args, timed_region)
+    if rank == 0 and single and not args.no_cpu_baseline:
+        base, want = cpu_baseline(dataset, model, args.kind, args.cpu_samples)
         out['cpu_baseline'] = base
         with torch.no_grad():                                 # same weights as the oracle run (Adam may have stepped above)
             got = model.forward().cpu().numpy()               # full-size parity of the fused table against the oracle
         out['parity_vs_cpu_oracle'] = {'max_abs_err': float(np.abs(got - want).max()),
                                        'max_abs_value': float(np.abs(want).max()), 'rows': int(want.shape[0])}
+    if single and not args.no_extras and args.preset == 'ml25m_shaped' and not args.metapaths and args.scale == 1.0:
+        del model
+        torch.cuda.empty_cache()
+        out['metapaths_13'] = thirteen_metapaths(dataset, args, device, batch, timed_region, not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def load_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), or None."""
-    path = os.path.join(ROOT, 'profiles', 'traffic.json')
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
-    except Exception:
-        return None
+def eval_variant(dataset, model, args, timed_region):
+    """SURVEY.md 8(d) "eval variant": one eval() forward (full graph) + the scoring of U x (1 + 99) candidates and the
+    rank / AUC / eval-loss reductions of solvers.py:56-96 for ALL users in one launch (pea_rank_eval); the timed
+    region ends with the rank vector on the device.  Candidate ids are drawn on the host beforehand (the reference draws
+    them with np.random.choice inside its loop; here uniform over the item block, vectorised)."""
+    from graph_recsys_benchmark_amd import engine
+    u_nids, cand = dataset.eval_candidates()
+    dev = model.x.device
+    u_t, c_t = torch.from_numpy(u_nids).to(dev), torch.from_numpy(cand).to(dev)
+
+    def run():
+        model.eval()
+        return engine.rank_eval(model.cached_repr, u_t, c_t, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias)
+
+    run()
+    steps = max(3, args.steps // 2)
+    dt, (scores, rank, auc, loss) = timed_region(run, steps)
+    dt /= steps
+    # parity of a sample of users against the CPU oracle's scorer on the SAME fused table (the table itself is checked
+    # at full size below): integer ranks equal unless two scores are closer than fp32 noise
+    from oracle import oracle as orc
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith('fc')}
+    table = model.cached_repr.cpu().numpy()
+    pick = np.linspace(0, len(u_nids) - 1, 256).astype(np.int64)
+    want = np.stack([orc.predict(table, np.full(cand.shape[1], u_nids[k]), cand[k], sd['fc1.weight'], sd['fc1.bias'],
+                                 sd['fc2.weight'], sd['fc2.bias']) for k in pick])
+    got = scores[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    want_rank = (want[:, 1:] > want[:, :1]).sum(axis=1)
+    got_rank = rank[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    model.train()
+    return {'ms': dt * 1e3, 'users': int(len(u_nids)), 'candidates_per_user': int(cand.shape[1]),
+            'edges_per_s': model._engine.messages / dt, 'scores_per_s': cand.size / dt,
+            'what': 'eval() forward over the full graph + pea_rank_eval of every user (rank, AUC, eval loss on device)',
+            'parity_vs_cpu_oracle': {'users_checked': int(pick.size), 'score_max_abs_err': float(np.abs(got - want).max()),
+                                     'ranks_differing': int((want_rank != got_rank).sum())}}
+
+
+def thirteen_metapaths(dataset, args, device, batch, timed_region, with_oracle):
+    """The reference's own 25m configuration runs all THIRTEEN metapaths of utils/general_utils.py:335-356
+    (experiments/scripts/script_movielens_25m.ps1:41); BASELINE.json's metric is quoted on the first nine.  Same step,
+    13 channels; the four extra channels (flip(user2item) -> user2item, tag2user -> user2item, and the two tag2item
+    endings) are checked against the CPU oracle at full size."""
+    dataset.spec = dict(dataset.spec, num_metapaths=13)
+    model = build_model(dataset, args.kind, device)
+    model.train()
+
+    def step():
+        with torch.no_grad():
+            return model.loss(batch)
+
+    for _ in range(3):
+        step()
+    steps = max(3, args.steps // 2)
+    dt, loss = timed_region(step, steps)
+    dt /= steps
+    out = {'ms_per_step': dt * 1e3, 'messages_per_step': model._engine.messages, 'edges_per_s': model._engine.messages / dt,
+           'loss': float(loss)}
+    if with_oracle:
+        extra = [9, 10, 11, 12]
+        outs, _, _ = oracle_channels(dataset, model, args.kind, extra)
+        with torch.no_grad():
+            _, stack = model.forward(return_stack=True)
+        got = stack[:, extra].cpu().numpy()
+        want = np.stack(outs, axis=1)
+        out['parity_vs_cpu_oracle'] = {'channels': [p + 1 for p in extra], 'max_abs_err': float(np.abs(got - want).max()),
+                                       'max_abs_value': float(np.abs(want).max())}
+    return out
 
 
 if __name__ == '__main__':

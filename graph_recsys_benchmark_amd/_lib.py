@@ -75,6 +75,7 @@ SIGNATURES = {
     'pea_model_set_active_rows': (_int, [_vp, _vp]),
     'pea_model_describe': (_int, [_vp, C.POINTER(_i64), _int, C.POINTER(_int)]),
     'pea_model_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    'pea_model_compulsory_bytes': (C.c_double, [_vp]),
     'pea_conv_workspace_bytes': (_sz, [_vp, _int, _int, _int, _int, _int]),
     'pea_gat_conv': (_int, [_vp, _int, _int, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, C.c_float, _int, _vp, _i64, _vp, _sz, _vp]),
     'pea_gcn_conv': (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _int, _int, _vp, _i64, _vp, _sz, _vp]),
@@ -91,6 +92,8 @@ SIGNATURES = {
     'pea_predict': (_int, [_i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pea_profile_enable': (_int, [_int]),
     'pea_profile_read': (_int, [_int, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(_int)]),
+    'pea_profile_read_ex': (_int, [_int, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), C.POINTER(_int)]),
     'pea_rank_eval': (_int, [_i64, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -366,11 +366,18 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     // algorithmic bytes of SURVEY.md 8(d) attributed to a launch: per message 4 B per gathered feature column
     // + 4 B source index + 4 B per attention scalar (GAT) / norm scalar (GCN), times the messages it reduces
     double bytes_short = 0.0, bytes_long = 0.0;
+    // ... and what the launch itself pulls through the memory system: every message's row chunk + its source index
+    // (GCN: + the norm scalar), each once; `table`: the largest gather footprint among the launch's groups
+    double pull_short = 0.0, pull_long = 0.0, table = 0.0;
     for (int i = 0; i < n_sel; ++i) {
         const AggGroup &g = base.g[sel[i]];
         const double per_msg = 4.0 * g.W + 4.0 * g.idx_share + (MODE == AGG_GAT ? 4.0 * (g.W / g.F) : MODE == AGG_GCN ? 4.0 * g.idx_share : 0.0);
         bytes_short += per_msg * g.msgs_short;
         bytes_long += per_msg * g.msgs_long;
+        const double pull = 4.0 * g.W + 4.0 + (MODE == AGG_GCN ? 4.0 : 0.0);
+        pull_short += pull * g.msgs_short;
+        pull_long += pull * g.msgs_long;
+        table = table > g.table_rows * 4.0 * g.W ? table : g.table_rows * 4.0 * g.W;
     }
     // short
     L.n_groups = 0;
@@ -384,7 +391,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     }
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
-        ProfScope ps(kname<G, MODE>(0), stream, bytes_short);
+        ProfScope ps(kname<G, MODE>(0), stream, bytes_short, pull_short, table);
         hipLaunchKernelGGL((agg_short_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
@@ -400,7 +407,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     }
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
-        ProfScope ps(kname<G, MODE>(1), stream, bytes_long);
+        ProfScope ps(kname<G, MODE>(1), stream, bytes_long, pull_long, table);
         hipLaunchKernelGGL((agg_long_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }

@@ -43,7 +43,10 @@ const char *get_error();
 bool prof_enabled();
 class ProfScope {
   public:
-    ProfScope(const char *name, hipStream_t stream, double units = 0.0);
+    // units: algorithmic bytes of SURVEY.md 8(d) attributed to the launch; gathered: bytes the launch itself must pull
+    // through the memory system (every message's row chunk + its source index, each once; rows served from an LDS
+    // image excluded); table: footprint of the table those rows come from (what decides the cache tier)
+    ProfScope(const char *name, hipStream_t stream, double units = 0.0, double gathered = 0.0, double table = 0.0);
     ~ProfScope();
   private:
     int idx_;
@@ -73,6 +76,7 @@ struct Relation {
     int slice_min = 0;
     int64_t slice_span = 1;
     int max_deg = 0;
+    int64_t src_span = 0;   // max - min + 1 over the source ids of the kept edges (footprint of the gather table in rows)
     int *rowptr = nullptr;  // device [N+1]
     int *col = nullptr;     // device [e_kept] source ids, destination-sorted, stable
     int *eid = nullptr;     // device [e_kept] original COO edge index of each CSR slot (PEA_PLAN_EDGE_IDS)
@@ -151,6 +155,7 @@ struct AggGroup {
     // bookkeeping for the live roofline measurement (messages reduced by the short / long launches; how many
     // reference conv calls share this group's index read)
     double msgs_short, msgs_long, idx_share;
+    double table_rows;   // rows of the table the gathers of this group read (source-id span of the relation, or slots)
     // training: per (row, head) softmax statistics (m in the log2 domain, S) written by the GAT forward
     float *stats;        // [N, ld_stats], already offset to this group's first head (2 floats per head)
     int ld_stats;

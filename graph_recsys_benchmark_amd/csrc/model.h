@@ -64,6 +64,7 @@ struct pea_model {
     size_t total_floats = 0;
     int64_t messages = 0;
     double alg_bytes = 0.0;
+    double compulsory_bytes = 0.0;        // HBM floor of one forward: every buffer of the schedule written once and read once
     bool single_conv = false;             // pea_*_conv: any output width, X goes to the caller's buffer
     bool backward = false;                // training buffers allocated
     // SAGE without training buffers runs on the GAT/GCN schedule: transform first (mean_j(W x_j) = W mean_j(x_j)), so the

@@ -66,6 +66,11 @@ int build_schedule(pea_model *m) {
     size_t pack = 0, ws = 0, partial_max = 0, xch = 0;
     m->messages = 0;
     m->alg_bytes = 0.0;
+    // Compulsory HBM bytes of THIS schedule (not of the reference's): x read once; per level T_s written once and read
+    // once (however often its rows are gathered afterwards: re-reads can come from cache), O_s of the channels that
+    // continue written once and read once, every group's index arrays read once; X written and read once; the fused
+    // table written once.  step time x 8 TB/s over this = how far the whole step is from the DRAM floor.
+    m->compulsory_bytes = 4.0 * (double)N * d.emb_dim;
 
     for (int s = 0; s < Smax; ++s) {
         Level &L = m->levels[(size_t)s];
@@ -251,6 +256,14 @@ int build_schedule(pea_model *m) {
         L.off_a = ws;
         L.off_o = ws;
         ws = pad_off(ws + (size_t)N * (size_t)L.ld_o);
+        {
+            double cont_cols = 0.0;
+            for (const Unit &u : L.units)
+                if (!u.last) cont_cols += u.HF;
+            m->compulsory_bytes += 8.0 * (double)N * L.n_cols + 8.0 * (double)N * cont_cols;
+            for (const GroupPlan &g : L.groups)
+                m->compulsory_bytes += 4.0 * (double)plan->rels[(size_t)g.rel].e_kept + 4.0 * ((double)N + 1.0);
+        }
         // statistics: messages and the algorithmic-byte yardstick of SURVEY.md 8(d)
         for (const Unit &u : L.units) {
             const Relation &R = plan->rels[(size_t)u.rel];
@@ -268,6 +281,7 @@ int build_schedule(pea_model *m) {
     }
     m->ld_x = pad_ld(x_cols);
     m->alg_bytes += 4.0 * (double)N * P * d.repr_dim + 4.0 * (double)N * d.repr_dim;
+    m->compulsory_bytes += 8.0 * (double)N * x_cols + 4.0 * (double)N * d.repr_dim;
     m->pack_floats = pad_off(pack);
     size_t off = m->pack_floats;
     for (Level &L : m->levels) {
@@ -476,6 +490,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 a.msgs_short = (double)R.edges_short + loops * a.n_short;
                 a.msgs_long = (double)R.edges_long + loops * R.n_direct;
                 a.idx_share = mode == AGG_MEAN ? 1.0 : (double)g.n_convs;
+                a.table_rows = via_slots ? (double)R.slots_per_rank * plan->shard_world : (double)R.src_span;
             }
             if (mean2) {
                 a.feat = via_slots ? wsf + g.xch_off : T + g.col;
@@ -768,6 +783,8 @@ extern "C" int pea_model_stats(const pea_model *model, int64_t *messages, double
     if (algorithmic_bytes) *algorithmic_bytes = model->alg_bytes;
     return PEA_OK;
 }
+
+extern "C" double pea_model_compulsory_bytes(const pea_model *model) { return model ? model->compulsory_bytes : 0.0; }
 
 float *aligned_ws(void *workspace) {
     return reinterpret_cast<float *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);

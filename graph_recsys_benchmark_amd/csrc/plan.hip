@@ -186,7 +186,9 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
         const char *env_e = getenv("PEA_SLICE_MIN_EDGES"), *env_b = getenv("PEA_SLICE_BYTES");
         const int64_t min_edges = env_e ? atoll(env_e) : kSliceMinEdges;
         const double slice_bytes = env_b ? atof(env_b) : kSliceBytes;
-        if (plan->gather_row_bytes > 0 && E >= min_edges) {
+        {
+            // source-id range of the kept edges: the footprint of the gather table (always recorded), and for large
+            // relations the span the source slices divide
             int h_mm[2] = {INT32_MAX, -1}, *mm = nullptr;
             PEA_HIP_C(hipMalloc((void **)&mm, 2 * sizeof(int)));
             PEA_HIP_C(hipMemcpyAsync(mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, stream));
@@ -196,8 +198,9 @@ int build_relation(pea_plan *plan, Relation &R, const int64_t *coo_dev, int64_t 
             (void)hipFree(mm);
             if (h_mm[1] >= h_mm[0]) {
                 const int64_t span = (int64_t)h_mm[1] - h_mm[0] + 1;
+                R.src_span = span;
                 const double footprint = (double)span * plan->gather_row_bytes;
-                if (footprint > 1.5 * slice_bytes) {
+                if (plan->gather_row_bytes > 0 && E >= min_edges && footprint > 1.5 * slice_bytes) {
                     const int phases = (int)std::min<double>(8.0, std::ceil(footprint / (8.0 * slice_bytes)));
                     S = 8 * phases;
                     R.slice_min = h_mm[0];

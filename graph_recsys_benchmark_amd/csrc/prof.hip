@@ -11,6 +11,7 @@ struct Rec {
     const char *name;
     hipEvent_t beg, end;
     double units;  // algorithmic bytes (or 0) attributed to the launch
+    double gathered, table;  // see ProfScope (common.h)
 };
 std::mutex g_mu;
 bool g_on = false;
@@ -31,10 +32,11 @@ static hipEvent_t get_event() {
     return e;
 }
 
-ProfScope::ProfScope(const char *name, hipStream_t stream, double units) : idx_(-1), stream_(stream) {
+ProfScope::ProfScope(const char *name, hipStream_t stream, double units, double gathered, double table)
+    : idx_(-1), stream_(stream) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r{name, get_event(), get_event(), units};
+    Rec r{name, get_event(), get_event(), units, gathered, table};
     (void)hipEventRecord(r.beg, stream);
     idx_ = (int)g_recs.size();
     g_recs.push_back(r);
@@ -56,7 +58,15 @@ extern "C" int pea_profile_enable(int on) {
 
 // Waits for every recorded launch, returns up to `max` records (name [32 bytes each], milliseconds, units)
 // in launch order, and clears the log.
+extern "C" int pea_profile_read_ex(int max, char *names, float *ms, double *units, double *gathered, double *table,
+                                   int *count);
+
 extern "C" int pea_profile_read(int max, char *names, float *ms, double *units, int *count) {
+    return pea_profile_read_ex(max, names, ms, units, nullptr, nullptr, count);
+}
+
+extern "C" int pea_profile_read_ex(int max, char *names, float *ms, double *units, double *gathered, double *table,
+                                   int *count) {
     std::lock_guard<std::mutex> lk(pea::g_mu);
     int n = 0;
     for (auto &r : pea::g_recs) {
@@ -69,6 +79,8 @@ extern "C" int pea_profile_read(int max, char *names, float *ms, double *units, 
             }
             if (ms) ms[n] = t;
             if (units) units[n] = r.units;
+            if (gathered) gathered[n] = r.gathered;
+            if (table) table[n] = r.table;
             ++n;
         }
         pea::g_pool.push_back(r.beg);

@@ -181,6 +181,7 @@ class PEAEngine:
         msgs, ab = C.c_int64(), C.c_double()
         _lib.check(lib.pea_model_stats(handle, C.byref(msgs), C.byref(ab)))
         self.messages, self.algorithmic_bytes = int(msgs.value), float(ab.value)
+        self.compulsory_bytes = float(lib.pea_model_compulsory_bytes(handle))   # HBM floor of one forward (bench.py)
         self.sharded = plan.shard[1] > 1
         self.n_stages = int(lib.pea_model_num_stages(handle))
         # float32 view of the workspace from its 256-byte aligned base (the exchanges index into it)

@@ -136,6 +136,13 @@ class SyntheticHIN:
         ei[1] = dst + self.type_accs[dst_t]
         return ei
 
+    def __getitem__(self, key):
+        """dataset['num_nodes'] -- the reference's Dataset returns attributes for str keys (datasets/movielens.py:1141-1142)
+        and the models read kwargs['dataset']['num_nodes'] (models/base.py:156)."""
+        if isinstance(key, str):
+            return getattr(self, key, None)
+        raise TypeError('SyntheticHIN is indexed by attribute name only')
+
     # ---- what the reference's experiment scripts would pass around (experiments/peagat_solver_bpr.py:70-104)
     def dataset_args(self):
         return {'dataset': self.spec['dataset'], 'name': self.spec['name']}
@@ -157,3 +164,34 @@ class SyntheticHIN:
         pick = rs.randint(0, u2i.shape[1], size=b)
         neg = rs.randint(low=self.type_accs['iid'], high=self.type_accs['iid'] + self.num_iids, size=(b, 1))
         return np.hstack([u2i[:, pick].T.astype(np.int64), neg.astype(np.int64)])
+
+    def eval_split(self, num_users=None, seed=2021):
+        """Leave-one-out evaluation maps in the reference's layout (datasets/movielens.py:304-308, read by
+        solvers.py:21-31,50-54): test_pos_unid_inid_map[u] = [one item u has not rated], neg_unid_inid_map[u] = every
+        other unrated item.  Per-user Python lists, so only for the first `num_users` users (all by default; the
+        25m-shaped preset would need 162 k x 59 k entries: use eval_candidates there).  Sets and returns both maps."""
+        rng = np.random.default_rng(seed)
+        u2i = self.edge_index_nps['user2item'].astype(np.int64)
+        u0, i0 = self.type_accs['uid'], self.type_accs['iid']
+        nu = self.num_uids if num_users is None else min(int(num_users), self.num_uids)
+        order = np.argsort(u2i[0], kind='stable')
+        starts = np.searchsorted(u2i[0][order], np.arange(u0, u0 + nu + 1))
+        self.test_pos_unid_inid_map, self.neg_unid_inid_map = {}, {}
+        items = np.arange(i0, i0 + self.num_iids)
+        for k in range(nu):
+            seen = u2i[1][order[starts[k]:starts[k + 1]]]
+            unseen = np.setdiff1d(items, seen, assume_unique=False)
+            j = int(rng.integers(0, unseen.size))
+            self.test_pos_unid_inid_map[u0 + k] = [int(unseen[j])]
+            self.neg_unid_inid_map[u0 + k] = [int(v) for v in np.delete(unseen, j)]
+        return self.test_pos_unid_inid_map, self.neg_unid_inid_map
+
+    def eval_candidates(self, num_users=None, num_neg=99, seed=2021):
+        """(u_nids [U], cand [U, 1 + num_neg]) int64 for the batched evaluator: column 0 the held-out positive, the rest
+        negatives drawn WITH replacement (solvers.py:29), all uniform over the item block -- the vectorised stand-in for
+        eval_split + generate_candidates at sizes where per-user Python lists are impractical (benchmarks)."""
+        rs = np.random.RandomState(seed)
+        nu = self.num_uids if num_users is None else min(int(num_users), self.num_uids)
+        lo = self.type_accs['iid']
+        cand = rs.randint(lo, lo + self.num_iids, size=(nu, 1 + num_neg)).astype(np.int64)
+        return np.arange(self.type_accs['uid'], self.type_accs['uid'] + nu, dtype=np.int64), cand

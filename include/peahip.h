@@ -226,6 +226,10 @@ int pea_model_exchange_desc(const pea_model *model, int level, int k, pea_exchan
 /* messages reduced by one forward (sum over channels/steps of kept edges + self loops), and the
  * algorithmic HBM bytes of SURVEY.md section 8(d) for this model -- the roofline yardstick. */
 int pea_model_stats(const pea_model *model, int64_t *messages, double *algorithmic_bytes);
+/* Compulsory HBM bytes of one forward of THIS schedule: x read once, every level buffer (T_s, O_s of the channels that
+ * continue, X) written once and read once, every aggregation group's index arrays read once, the fused table written
+ * once.  step time x 8 TB/s over this number = distance of the whole step from the DRAM floor (bench.py `hbm_floor`). */
+double pea_model_compulsory_bytes(const pea_model *model);
 
 /* ------------------------------------------------------------------------------------------------
  * Single conv layers (the drop-in GATConv/GCNConv/SAGEConv modules call these).
@@ -306,6 +310,11 @@ int pea_rank_eval(int64_t U, int C, int R, int64_t num_nodes, const float *repr,
  * ---------------------------------------------------------------------------------------------- */
 int pea_profile_enable(int on);
 int pea_profile_read(int max_records, char *names_host, float *ms_host, double *bytes_host, int *count_host);
+/* The same, with two more per-launch figures of the aggregation kernels: `gathered` = bytes the launch itself must
+ * pull through the memory system (row chunk + source index of every message, each once), `table` = footprint in bytes
+ * of the largest table those rows come from (decides the cache tier the gather is served from). */
+int pea_profile_read_ex(int max_records, char *names_host, float *ms_host, double *bytes_host, double *gathered_host,
+                        double *table_host, int *count_host);
 
 #ifdef __cplusplus
 }

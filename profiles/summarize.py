@@ -60,9 +60,42 @@ def main(root):
     return out
 
 
+BENCH_NAME = {'gemm_persist_k32': 'gemm_mfma_shared', 'gemm_skinny_k4': 'gemm_mfma_narrow'}   # names bench.py prints
+
+
+def merge_traffic(res, key, source):
+    """profiles/traffic.json[key] = per-kernel fabric bytes per launch + L2 hit rate, key = '<preset>/<kind>': what
+    bench.py reports as roofline.traffic for THAT workload (and nothing for any other)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'traffic.json')
+    try:
+        tab = json.load(open(path))
+    except Exception:
+        tab = {}
+    if any(not isinstance(v, dict) or 'avg_ms' in v for k, v in tab.items() if not k.startswith('_')):
+        tab = {}                                   # round-1 layout (keyed by kernel name only): start over
+    tab['_doc'] = ('keys: <preset>/<kind> of a full-scale single-GPU bench.py run; per kernel (bench.py names): bytes = '
+                   '(2*FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes (FETCH doubled on gfx950 per '
+                   'guides/MI355X_MICROARCH.md); fabric-side bytes, Infinity-Cache hits included (upper bound on DRAM)')
+    entry = {'_source': source}
+    for k, v in res.items():
+        if 'hbm_bytes_per_launch' not in v:
+            continue
+        entry[BENCH_NAME.get(k, k)] = {a: v[a] for a in ('avg_ms', 'hbm_bytes_per_launch', 'l2_hit_rate', 'calls') if a in v}
+    tab[key] = entry
+    json.dump(tab, open(path, 'w'), indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-    res = main(sys.argv[1])
-    if len(sys.argv) > 2:
-        json.dump(res, open(sys.argv[2], 'w'), indent=1, sort_keys=True)
+    argv = list(sys.argv[1:])
+    traffic_key = None
+    if '--traffic' in argv:
+        i = argv.index('--traffic')
+        traffic_key = argv[i + 1]
+        del argv[i:i + 2]
+    res = main(argv[0])
+    if len(argv) > 1:
+        json.dump(res, open(argv[1], 'w'), indent=1, sort_keys=True)
+    if traffic_key:
+        merge_traffic(res, traffic_key, argv[1] if len(argv) > 1 else argv[0])
     for k, v in sorted(res.items(), key=lambda kv: -kv[1].get('avg_ms', 0)):
         print('%-24s %s' % (k, {a: (round(b, 4) if isinstance(b, float) and b < 1e4 else (int(b) if isinstance(b, float) else b)) for a, b in v.items()}))
