@@ -354,7 +354,10 @@ def check_pending_errors():
     bpr_score(validate=True)); until then the loss of such a batch is NaN, never a silently smaller sum."""
     global _pending_err
     flags, _pending_err = _pending_err, []
-    if flags and int(torch.stack(flags).max().item()) != 0:
+    if flags and int(torch.stack([f.reshape(-1)[0] for f in flags]).max().item()) != 0:
+        for f in flags:
+            if f.numel() == 1 and f.dim() == 1:
+                f.zero_()          # a persistent flag (sharding.ShardLayout) is re-armed
         raise IndexError('index out of range in BPR triples')
 
 

@@ -11,11 +11,19 @@ of both conv layers, so (a) the heavy relations shard evenly without a cost mode
   * the fused [N, R] table before scoring (instead of the reference-literal [P, N, R] stack: same arithmetic,
     P times fewer bytes over xGMI).
 
-Everything here is torch index arithmetic (device agnostic) so the layouts and exchanges are exercised on CPU with
-the gloo backend (tests/test_sharding_cpu.py); on the GPU box the same code runs over RCCL (backend 'nccl').
+The layout math is torch index arithmetic (device agnostic) and runs once, at plan time.  Per step, on CUDA tensors,
+rows are packed into / unpacked from preallocated rank-major buffers by the HIP kernels of csrc/exchange.hip on the
+launch stream and the all-gather runs IN PLACE on that buffer (no staging allocation, no clone); on CPU tensors the same
+moves are torch index ops, so layouts and exchanges are exercised with the gloo backend (tests/test_sharding_cpu.py).
+On the GPU box the collectives run over RCCL (backend 'nccl').
 """
 import torch
 import torch.distributed as dist
+
+
+def _hip():
+    from . import _lib
+    return _lib
 
 
 class CommTimer:
@@ -61,6 +69,7 @@ class SourceLayout:
         self.slot_of_node[src_nodes] = slots.to(torch.int32)
         mine = owners == shard.rank
         self.own_nodes = src_nodes[mine]                            # ascending == slot order inside this rank
+        self.own_nodes_i32 = self.own_nodes.to(torch.int32).contiguous()   # what the HIP pack kernel reads
         self.own_count = int(self.own_nodes.numel())
         self.need_rows = torch.unique(torch.cat([shard.owned_rows(src_nodes.device), src_nodes])).to(torch.int32)
 
@@ -72,6 +81,7 @@ class ShardLayout:
         self.num_nodes, self.rank, self.world, self.tile = int(num_nodes), int(rank), int(world), int(tile)
         self._owned = {}
         self._gather_plan = {}
+        self._flags = {}
         self.dry = False   # True: skip the collectives (single-process rehearsal of one rank's compute + host work)
 
     def owner(self, nodes):
@@ -99,8 +109,9 @@ class ShardLayout:
         mine = buf[self.rank * block_rows:(self.rank + 1) * block_rows]
         done = CommTimer.span(buf.device)
         if dist.get_backend(group) == 'nccl':
-            # RCCL all-gather; the send block is copied out first so input and output never alias
-            dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1).clone(), group=group)
+            # RCCL all-gather IN PLACE: the send block is this rank's slice of the receive buffer (ncclAllGather's
+            # documented in-place form, sendbuff == recvbuff + rank * count)
+            dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=group)
         else:                                                                          # gloo (CPU tests / rehearsal)
             parts = [torch.empty(mine.shape, dtype=buf.dtype) for _ in range(self.world)]
             dist.all_gather(parts, mine.detach().cpu().contiguous(), group=group)
@@ -116,18 +127,35 @@ class ShardLayout:
         if m == 0:
             return
         if layout.own_count:
-            xbuf[self.rank * m:self.rank * m + layout.own_count, :width] = table[layout.own_nodes, col:col + width]
+            if table.is_cuda:
+                lib = _hip()
+                lib.check(lib.load().pea_rows_pack(lib.ptr(table), table.stride(0), int(col), int(width),
+                                                   lib.ptr(layout.own_nodes_i32), layout.own_count,
+                                                   lib.ptr(xbuf[self.rank * m:]), xbuf.stride(0), lib.current_stream()))
+            else:
+                xbuf[self.rank * m:self.rank * m + layout.own_count, :width] = table[layout.own_nodes, col:col + width]
         self._all_gather_blocks(xbuf, m, group)
 
     def gather_rows(self, table, ids, group=None):
         """[len(ids), ...] rows table[ids] where every rank only holds the rows it owns: each rank contributes its own
         rows (zeros elsewhere) and the contributions are summed -- one small all-reduce instead of the all-gather of
         the whole table when only a batch of rows is needed (the BPR triples of a training step).  x + 0 is exact."""
-        rows = table[ids]
         if self.world == 1:
-            return rows
-        mine = self.owner(ids) == self.rank       # rows of other ranks are undefined here (may hold NaN): select, never scale
-        rows = torch.where(mine.view(-1, *([1] * (rows.dim() - 1))), rows, torch.zeros((), dtype=rows.dtype, device=rows.device))
+            return table[ids]
+        if table.is_cuda and table.dim() == 2 and table.shape[1] % 4 == 0 and table.stride(1) == 1 and ids.dim() == 1:
+            # one HIP launch: rows this rank owns, zeros elsewhere (an id out of range sets the flag; IndexError at the
+            # next engine.check_pending_errors(), like a bad BPR triple)
+            lib = _hip()
+            ids = ids if ids.dtype == torch.int64 else ids.to(torch.int64)
+            rows = torch.empty((ids.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
+            flag = self._err_flag(table.device)
+            lib.check(lib.load().pea_rows_select_owned(lib.ptr(table), table.stride(0), table.shape[1], table.shape[0],
+                                                       lib.ptr(ids), ids.stride(0), ids.numel(), self.rank, self.world,
+                                                       self.tile, lib.ptr(rows), lib.ptr(flag), lib.current_stream()))
+        else:
+            rows = table[ids]
+            mine = self.owner(ids) == self.rank   # rows of other ranks are undefined here (may hold NaN): select, never scale
+            rows = torch.where(mine.view(-1, *([1] * (rows.dim() - 1))), rows, torch.zeros((), dtype=rows.dtype, device=rows.device))
         if self.dry:
             return rows
         done = CommTimer.span(rows.device)
@@ -141,23 +169,46 @@ class ShardLayout:
             done.record()
         return rows
 
+    def _err_flag(self, device):
+        from . import engine
+        key = str(device)
+        if key not in self._flags:
+            self._flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        flag = self._flags[key]
+        if not any(f is flag for f in engine._pending_err):
+            engine._pending_err.append(flag)
+        return flag
+
     def allgather_rows(self, table, group=None):
-        """table [N, ...]: every rank has written the rows it owns; fills in everybody else's (in place)."""
+        """table [N, ...]: every rank has written the rows it owns; fills in everybody else's (in place).  The rank-major
+        staging buffer and the row lists are built once per (device, row width) and reused."""
         if self.world == 1:
             return table
         dev = table.device
-        key = str(dev)
+        flat = table.reshape(self.num_nodes, -1)
+        width = flat.shape[1]
+        key = (str(dev), width, table.dtype)
         if key not in self._gather_plan:
             rows = [self.rows_of(r, dev) for r in range(self.world)]
             m = max(int(x.numel()) for x in rows)
             dest = torch.cat([x for r, x in enumerate(rows) if r != self.rank])
             src = torch.cat([r * m + torch.arange(x.numel(), device=dev) for r, x in enumerate(rows) if r != self.rank])
-            self._gather_plan[key] = (m, dest, src)
-        m, dest, src = self._gather_plan[key]
-        flat = table.reshape(self.num_nodes, -1)
-        buf = torch.zeros((self.world * m, flat.shape[1]), dtype=table.dtype, device=dev)
+            buf = torch.zeros((self.world * m, width), dtype=table.dtype, device=dev)
+            self._gather_plan[key] = (m, dest, src, dest.to(torch.int32), src.to(torch.int32), buf,
+                                      self.owned_rows(dev).to(torch.int32).contiguous())
+        m, dest, src, dest32, src32, buf, own32 = self._gather_plan[key]
         own = self.owned_rows(dev)
-        buf[self.rank * m:self.rank * m + own.numel()] = flat[own]
+        hip = flat.is_cuda and flat.dtype == torch.float32 and width % 4 == 0 and flat.stride(1) == 1 and flat.stride(0) % 4 == 0
+        if hip:
+            lib = _hip()
+            lib.check(lib.load().pea_rows_pack(lib.ptr(flat), flat.stride(0), 0, width, lib.ptr(own32), own32.numel(),
+                                               lib.ptr(buf[self.rank * m:]), buf.stride(0), lib.current_stream()))
+        else:
+            buf[self.rank * m:self.rank * m + own.numel()] = flat[own]
         self._all_gather_blocks(buf, m, group)
-        flat[dest] = buf[src]
+        if hip:
+            lib.check(lib.load().pea_rows_unpack(lib.ptr(buf), buf.stride(0), lib.ptr(src32), width, lib.ptr(dest32),
+                                                 dest32.numel(), lib.ptr(flat), flat.stride(0), 0, lib.current_stream()))
+        else:
+            flat[dest] = buf[src]
         return table

@@ -303,6 +303,24 @@ int pea_rank_eval(int64_t U, int C, int R, int64_t num_nodes, const float *repr,
                   float *loss, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange helpers (one process per GPU; the collectives themselves are RCCL calls made by the host
+ * mirror, graph_recsys_benchmark_amd/sharding.py).  No counterpart in the reference (single-process forward,
+ * models/base.py:191-206).  All widths / strides / columns in floats, multiples of 4.
+ *   pea_rows_pack    dst[k, 0:width]                = table[nodes[k], col:col+width]
+ *   pea_rows_unpack  table[nodes[k], col:col+width] = src[src_rows ? src_rows[k] : k, 0:width]
+ *   pea_rows_select_owned  out[k, 0:width] = ((ids[k*id_stride] / tile) % world == rank) ? table[ids[..], 0:width] : 0
+ *                    (the batch rows a rank contributes to the loss all-reduce; *err_flag |= 1 for an id outside
+ *                    [0, num_nodes), device int32 owned by the caller)
+ * ---------------------------------------------------------------------------------------------- */
+int pea_rows_pack(const float *table, int64_t ld, int col, int width, const int32_t *nodes, int64_t n, float *dst,
+                  int64_t dst_ld, void *stream);
+int pea_rows_unpack(const float *src, int64_t src_ld, const int32_t *src_rows, int width, const int32_t *nodes, int64_t n,
+                    float *table, int64_t ld, int col, void *stream);
+int pea_rows_select_owned(const float *table, int64_t ld, int width, int64_t num_nodes, const int64_t *ids,
+                          int64_t id_stride, int64_t n, int rank, int world, int tile, float *out, int32_t *err_flag,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Live per-launch timing (bench.py's roofline leg): when enabled every kernel launch of the library is
  * bracketed by HIP events on the caller's stream.  pea_profile_read waits for them and returns, in launch
  * order, name (32 bytes each), milliseconds and the algorithmic bytes attributed to the launch; it clears

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_fp32_close, build_model, f64_forward, random_state_dict
+from helpers import assert_fp32_close, assert_fused_close, build_model, f64_forward, random_state_dict
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +30,7 @@ def _check(kind, n, edges, steps, emb, hidden, repr_dim, heads=1, aggr='att', se
     want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, hls, att=sd.get('att'), channel_aggr=aggr, return_stack=True)
     t_fused, t_stack = f64_forward(kind, sd, edges, steps, heads, aggr)
     assert_fp32_close(_np(stack), wstack, t_stack, what='stack')
-    assert_fp32_close(_np(fused), want, t_fused, what='fused')
+    assert_fused_close(_np(fused), _np(stack), want, t_fused, sd.get('att'), aggr)
     return model
 
 
