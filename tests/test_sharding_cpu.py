@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the row-ownership and exchange layouts of the multi-GPU forward
+"""CPU, world_size 2 and 4, gloo: the row-ownership and exchange layouts of the multi-GPU forward
 (graph_recsys_benchmark_amd/sharding.py) -- the same code that runs over RCCL on the GPUs."""
 import os
 import socket
@@ -90,6 +90,12 @@ def _worker(rank, world, port, tile):
 @pytest.mark.parametrize('tile', [64, 256])
 def test_sharding_layouts_world2_gloo(tile):
     mp.spawn(_worker, args=(2, _free_port(), tile), nprocs=2, join=True)
+
+
+def test_sharding_layouts_world4_gloo():
+    """Four ranks (the 4-GPU point of the scaling curve): same layouts and exchanges, tile 64 so every rank owns rows
+    of every node type of the small test graph."""
+    mp.spawn(_worker, args=(4, _free_port(), 64), nprocs=4, join=True)
 
 
 def test_single_rank_is_identity():
