@@ -471,13 +471,41 @@ def thirteen_metapaths(dataset, args, device, batch, timed_region, with_oracle):
            'loss': float(loss)}
     if with_oracle:
         extra = [9, 10, 11, 12]
-        outs, _, _ = oracle_channels(dataset, model, args.kind, extra)
+        outs, _, sd = oracle_channels(dataset, model, args.kind, extra)
         with torch.no_grad():
             _, stack = model.forward(return_stack=True)
         got = stack[:, extra].cpu().numpy()
         want = np.stack(outs, axis=1)
         out['parity_vs_cpu_oracle'] = {'channels': [p + 1 for p in extra], 'max_abs_err': float(np.abs(got - want).max()),
                                        'max_abs_value': float(np.abs(want).max())}
+        if args.kind in ('gat', 'sage'):
+            # Metapath 10 ends in user2item: its hottest items reduce up to ~2 M messages each, which the reference's
+            # fp32 scatter (and so the CPU oracle) sums SEQUENTIALLY, while the HIP path folds 512-edge chunks.  Which
+            # side carries the difference is settled in float64 on that one layer with IDENTICAL fp32 inputs for all
+            # three: the oracle's own first-layer output h1 -> HIP conv drop-in / fp32 oracle / float64 (oracle/rows64.py)
+            # at sampled item rows, the hottest included.
+            from oracle import oracle as orc
+            from oracle.rows64 import f64_rows_one_step
+            from graph_recsys_benchmark_amd.utils import metapath_table
+            p = 9
+            (r1, f1), (r2, f2) = metapath_table(dataset.dataset_args())[p]
+            rel = lambda r, f: np.ascontiguousarray(dataset.edge_index_nps[r].astype(np.int64)[::-1]) if f else dataset.edge_index_nps[r].astype(np.int64)
+            lps = [{k.split('gnn_layers.%d.' % s_)[1]: v for k, v in sd.items()
+                    if k.startswith('pea_channels.%d.gnn_layers.%d.' % (p, s_))} for s_ in range(2)]
+            h1 = orc.relu_(orc.conv(args.kind, sd['x'], rel(r1, f1), lps[0], 1))
+            e2 = rel(r2, f2)
+            want2 = orc.conv(args.kind, h1, e2, lps[1], 1)
+            with torch.no_grad():
+                got2 = model.pea_channels[p].gnn_layers[1](torch.from_numpy(h1).to(device), model.meta_path_edge_index_list[p][1]).cpu().numpy()
+            deg = np.bincount(e2[1], minlength=dataset.num_nodes)
+            order = np.argsort(-deg)
+            rows = np.unique(np.concatenate([order[:8], order[100:104], np.random.default_rng(7).choice(order[:dataset.num_iids], 16)]))
+            truth = f64_rows_one_step(args.kind, lps[1], h1, e2, rows)
+            out['last_layer_of_metapath_10_vs_float64'] = {
+                'rows': int(rows.size), 'max_messages_per_row': int(deg.max()),
+                'hip_max_abs_err': float(np.abs(got2[rows] - truth).max()),
+                'cpu_oracle_fp32_max_abs_err': float(np.abs(want2[rows] - truth).max()),
+                'max_abs_value': float(np.abs(truth).max())}
     return out
 
 

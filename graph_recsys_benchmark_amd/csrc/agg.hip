@@ -14,6 +14,8 @@
 //                 ids coalesced, the 64/G subgroups take them round-robin, partial states are merged
 //                 with xor shuffles
 //   hub rows    : chunks write (m, s, acc) records; a merge kernel folds them in chunk order
+#include <algorithm>
+
 #include "agg_common.h"
 
 namespace pea {
@@ -149,23 +151,22 @@ __global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
 // ------------------------------------------------------------------------------------------------
 // long rows and hub chunks: one wave per item
 // ------------------------------------------------------------------------------------------------
-template <int G, int MODE, int F4T>
-__global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
+// HOT: the K most frequent sources of the relation sit in the workgroup's LDS image (K rows x W columns, filled once per
+// workgroup); a CSR entry <= -2 names image row -(j + 2), anything >= 0 is read from memory as before.  Same edges, same
+// order, same values: results are bitwise those of the plain kernel.
+template <int G, int MODE, int F4T, int U, bool HOT>
+__device__ __forceinline__ void long_item(const AggGroup &P, const LongItem it, const int lane, const float4 *img,
+                                          const float *hot_dinv) {
     constexpr int NSG = kWave / G;
-    const int gi = find_group(L);
-    const AggGroup &P = L.g[gi];
-    const int wave = (int)threadIdx.x / kWave;
-    const int lane = (int)threadIdx.x % kWave;
-    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + wave;
-    if (item >= P.n_long) return;  // wave-uniform
-    const LongItem it = P.long_items[item];
-    if (it.slot == -2) return;  // padding of the XCD-affine item layout (plan.hip)
     const int sub = lane / G, sl = lane % G;
     const bool active = sl * 4 < P.W;
     const int c4 = active ? sl * 4 : 0;
     const float *feat = P.feat + c4;
     const float *feat_self = P.feat_self + c4;
     const int row = it.row;
+    const int *col = HOT ? P.hot_col : P.col;
+    const int W4 = P.W / 4;
+    const int lc = active ? sl : 0;   // this lane's float4 column inside an image row
 
     Soft st;
     st.init();
@@ -183,11 +184,11 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     } else if (MODE == AGG_GCN) {
         di = P.dinv_self[row];
     }
-    constexpr int U = 4;  // edges in flight per subgroup: U*NSG gathered rows per wave before the first use
-    int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
+    // edges in flight per subgroup: U*NSG gathered rows per wave before the first use
+    int src = it.beg + lane < it.end ? col[it.beg + lane] : -1;
     for (int base = it.beg; base < it.end; base += kWave) {
         const int nxt = base + kWave + lane;
-        const int src_next = nxt < it.end ? P.col[nxt] : -1;  // next batch of ids is in flight during this one
+        const int src_next = nxt < it.end ? col[nxt] : -1;  // next batch of ids is in flight during this one
         const int cnt = min(kWave, it.end - base);
         for (int t = 0; t < cnt; t += NSG * U) {
             int jj[U];
@@ -198,13 +199,19 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
             for (int u = 0; u < U; ++u) {
                 const int idx = t + u * NSG + sub;
                 const int j = __shfl(src, idx & (kWave - 1));
-                ok[u] = idx < cnt && j >= 0;
+                ok[u] = idx < cnt && j != -1;
                 jj[u] = ok[u] ? j : 0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
-                if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
+                if (HOT && jj[u] < 0) {  // image row (ds_read_b128), no memory traffic
+                    const int r = -(jj[u] + 2);
+                    h[u] = img[r * W4 + lc];
+                    if (MODE == AGG_GCN) a[u] = hot_dinv[r];
+                } else {
+                    h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
+                    if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
+                }
                 if (MODE == AGG_WSUM) a[u] = ok[u] ? P.edge_w[P.eid[base + t + u * NSG + sub]] : 0.f;
             }
             if (MODE == AGG_GAT) {
@@ -212,24 +219,28 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
                 for (int u = 0; u < U; ++u) a[u] = head_sum<F4T>(dot4(h[u], att_s), lane, pos, F4, pow2);
             }
             if (MODE == AGG_GAT) {
-                // one softmax update for the U edges: shared new max, one rescale of the state, U weights
-                float e[U];
-                float mn = st.m;
+                // softmax updates in batches of 4 edges (the batch size is part of the arithmetic: it stays 4 whatever
+                // U is, so every variant of the kernel produces the same bits): shared new max, one rescale, 4 weights
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float z = leaky(a[u] + a_d, slope);                   // computed for every slot, then selected:
-                e[u] = ok[u] ? z : -INFINITY;                                // no branch, 2^(-inf - m) = 0
-                    mn = fmaxf(mn, e[u]);
-                }
-                const float fs = __builtin_amdgcn_exp2f(st.m - mn);
-                st.m = mn;
-                st.s *= fs;
-                st.acc = scale4(st.acc, fs);
+                for (int u0 = 0; u0 < U; u0 += 4) {
+                    float e[4];
+                    float mn = st.m;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float p = __builtin_amdgcn_exp2f(e[u] - mn);  // 0 for the masked slots (mn is finite)
-                    st.s += p;
-                    st.acc = fma4(p, h[u], st.acc);
+                    for (int u = 0; u < 4; ++u) {
+                        const float z = leaky(a[u0 + u] + a_d, slope);          // computed for every slot, then selected:
+                        e[u] = ok[u0 + u] ? z : -INFINITY;                       // no branch, 2^(-inf - m) = 0
+                        mn = fmaxf(mn, e[u]);
+                    }
+                    const float fs = __builtin_amdgcn_exp2f(st.m - mn);
+                    st.m = mn;
+                    st.s *= fs;
+                    st.acc = scale4(st.acc, fs);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float p = __builtin_amdgcn_exp2f(e[u] - mn);  // 0 for the masked slots (mn is finite)
+                        st.s += p;
+                        st.acc = fma4(p, h[u0 + u], st.acc);
+                    }
                 }
             } else {
 #pragma unroll
@@ -282,6 +293,52 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
         }
     }
     if (sub == 0 && active) finish_row<MODE>(P, row, c4, it.end - it.beg, st, sum);
+}
+
+template <int G, int MODE, int F4T>
+__global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int wave = (int)threadIdx.x / kWave;
+    const int lane = (int)threadIdx.x % kWave;
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + wave;
+    if (item >= P.n_long) return;  // wave-uniform
+    const LongItem it = P.long_items[item];
+    if (it.slot == -2) return;  // padding of the XCD-affine item layout (plan.hip)
+    long_item<G, MODE, F4T, 4, false>(P, it, lane, nullptr, nullptr);
+}
+
+// One 1024-thread workgroup per CU, persistent: it fills the LDS image once, then its 16 waves walk the item list.  The
+// walk keeps the launch order's placement: the plain kernel hands items [4b, 4b + 4) to workgroup b, workgroups are dealt
+// round-robin over the 8 XCDs, and the plan lays sliced hub rows out so that workgroup b works on source slice b % 8.  Here
+// physical workgroup B plays the virtual workgroups  v = B % 8 + 8 * (4 * (B / 8) + wave / 4) + k * 4 * gridDim
+// (v % 8 == B % 8: same XCD as before; the grid is a multiple of 8).
+constexpr int kHotBlock = 1024;
+constexpr int kHotU = 8;
+template <int G, int MODE, int F4T>
+__global__ __launch_bounds__(kHotBlock) void agg_long_hot_kernel(const AggLaunch L) {
+    extern __shared__ float4 hot_img[];
+    const AggGroup &P = L.g[0];
+    const int W4 = P.W / 4;
+    for (int idx = (int)threadIdx.x; idx < P.hot_K * W4; idx += kHotBlock) {
+        const int r = idx / W4, c = idx - r * W4;
+        hot_img[idx] = ld4(row_at(P.feat, P.hot_nodes[r], P.ld_feat) + 4 * c);
+    }
+    float *hot_dinv = reinterpret_cast<float *>(hot_img + P.hot_K * W4);
+    if (MODE == AGG_GCN)
+        for (int r = (int)threadIdx.x; r < P.hot_K; r += kHotBlock) hot_dinv[r] = P.dinv[P.hot_nodes[r]];
+    __syncthreads();
+    const int wave = (int)threadIdx.x / kWave;
+    const int lane = (int)threadIdx.x % kWave;
+    const int n_virtual = (P.n_long + 3) / 4;
+    const int stride = (int)gridDim.x * 4;
+    for (int v = (int)blockIdx.x % 8 + 8 * (4 * ((int)blockIdx.x / 8) + wave / 4); v < n_virtual; v += stride) {
+        const int item = v * 4 + wave % 4;
+        if (item >= P.n_long) continue;
+        const LongItem it = P.long_items[item];
+        if (it.slot == -2) continue;
+        long_item<G, MODE, F4T, kHotU, true>(P, it, lane, hot_img, hot_dinv);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -346,15 +403,15 @@ __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
 }
 
 
-// kernel names as rocprofv3 would group them: agg_{short,long,merge}_g<G>_{gat,gcn,mean}
+// kernel names as rocprofv3 would group them: agg_{short,long,merge,longhot}_g<G>_{gat,gcn,mean}
 template <int G, int MODE>
 const char *kname(int which) {
-    static char names[3][32];
+    static char names[4][32];
     static bool init = false;
     if (!init) {
-        const char *w[3] = {"short", "long", "merge"};
+        const char *w[4] = {"short", "long", "merge", "longhot"};
         const char *m = MODE == AGG_GAT ? "gat" : MODE == AGG_GCN ? "gcn" : MODE == AGG_WSUM ? "wsum" : "mean";
-        for (int i = 0; i < 3; ++i) snprintf(names[i], sizeof(names[i]), "agg_%s_g%d_%s", w[i], G, m);
+        for (int i = 0; i < 4; ++i) snprintf(names[i], sizeof(names[i]), "agg_%s_g%d_%s", w[i], G, m);
         init = true;
     }
     return names[which];
@@ -365,18 +422,16 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     AggLaunch L;
     // algorithmic bytes of SURVEY.md 8(d) attributed to a launch: per message 4 B per gathered feature column
     // + 4 B source index + 4 B per attention scalar (GAT) / norm scalar (GCN), times the messages it reduces
-    double bytes_short = 0.0, bytes_long = 0.0;
+    double bytes_short = 0.0;
     // ... and what the launch itself pulls through the memory system: every message's row chunk + its source index
     // (GCN: + the norm scalar), each once; `table`: the largest gather footprint among the launch's groups
-    double pull_short = 0.0, pull_long = 0.0, table = 0.0;
+    double pull_short = 0.0, table = 0.0;
     for (int i = 0; i < n_sel; ++i) {
         const AggGroup &g = base.g[sel[i]];
         const double per_msg = 4.0 * g.W + 4.0 * g.idx_share + (MODE == AGG_GAT ? 4.0 * (g.W / g.F) : MODE == AGG_GCN ? 4.0 * g.idx_share : 0.0);
         bytes_short += per_msg * g.msgs_short;
-        bytes_long += per_msg * g.msgs_long;
         const double pull = 4.0 * g.W + 4.0 + (MODE == AGG_GCN ? 4.0 : 0.0);
         pull_short += pull * g.msgs_short;
-        pull_long += pull * g.msgs_long;
         table = table > g.table_rows * 4.0 * g.W ? table : g.table_rows * 4.0 * g.W;
     }
     // short
@@ -398,17 +453,46 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     // long + hub chunks
     L.n_groups = 0;
     blocks = 0;
+    double pull_plain = 0.0, alg_plain = 0.0;
     for (int i = 0; i < n_sel; ++i) {
         const AggGroup &g = base.g[sel[i]];
-        if (g.n_long <= 0) continue;
+        if (g.n_long <= 0 || g.hot_col) continue;
         L.blk_start[L.n_groups] = blocks;
         L.g[L.n_groups++] = g;
         blocks += ((g.n_long + 3) / 4 + 7) / 8 * 8;  // groups start on a multiple of 8 workgroups (XCD round-robin)
+        const double per_msg = 4.0 * g.W + 4.0 * g.idx_share + (MODE == AGG_GAT ? 4.0 * (g.W / g.F) : MODE == AGG_GCN ? 4.0 * g.idx_share : 0.0);
+        alg_plain += per_msg * g.msgs_long;
+        pull_plain += (4.0 * g.W + 4.0 + (MODE == AGG_GCN ? 4.0 : 0.0)) * g.msgs_long;
     }
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
-        ProfScope ps(kname<G, MODE>(1), stream, bytes_long, pull_long, table);
+        ProfScope ps(kname<G, MODE>(1), stream, alg_plain, pull_plain, table);
         hipLaunchKernelGGL((agg_long_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        PEA_HIP(hipGetLastError());
+    }
+    // groups with an LDS image of their hottest sources: one persistent launch each
+    for (int i = 0; i < n_sel; ++i) {
+        const AggGroup &g = base.g[sel[i]];
+        if (g.n_long <= 0 || !g.hot_col) continue;
+        if (MODE == AGG_WSUM) return PEA_ERR_ARG;  // never planned (per-edge weights are indexed by CSR slot)
+        L.n_groups = 1;
+        L.blk_start[0] = 0;
+        L.g[0] = g;
+        const size_t lds = (size_t)g.hot_K * g.W * sizeof(float) + (MODE == AGG_GCN ? (size_t)g.hot_K * sizeof(float) : 0);
+        static size_t lds_set = 0;  // per instantiation: raise the dynamic-LDS cap once (160 KiB per workgroup on gfx950)
+        if (lds > lds_set) {
+            PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_long_hot_kernel<G, MODE, F4T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        const int n_virtual = (g.n_long + 3) / 4;
+        const int grid = std::max(8, std::min(256, (n_virtual + 3) / 4 + 7 & ~7));
+        const double per_msg = 4.0 * g.W + 4.0 * g.idx_share + (MODE == AGG_GAT ? 4.0 * (g.W / g.F) : MODE == AGG_GCN ? 4.0 * g.idx_share : 0.0);
+        // pulled through the memory system: the cold rows, every index, and one image fill per workgroup
+        const double pull = (4.0 * g.W + (MODE == AGG_GCN ? 4.0 : 0.0)) * g.msgs_long * (1.0 - g.hot_frac) + 4.0 * g.msgs_long +
+                            (double)grid * (double)lds;
+        ProfScope ps(kname<G, MODE>(3), stream, per_msg * g.msgs_long, pull, g.table_rows * 4.0 * g.W);
+        hipLaunchKernelGGL((agg_long_hot_kernel<G, MODE, F4T>), dim3(grid), dim3(kHotBlock), lds, stream, L);
         PEA_HIP(hipGetLastError());
     }
     // hub merge

@@ -69,6 +69,17 @@ struct LongItem {
     int row, beg, end, slot;
 };
 
+// LDS-staged hot sources of one relation (plan.hip: ensure_hot): the K most frequent gather sources get rank 0..K-1;
+// `col` holds, per CSR slot, either the plain source id / exchange slot (>= 0) or -(rank + 2) for a hot source, so the
+// kernel knows without a lookup whether the row sits in its workgroup's LDS image (-1 stays the "no edge" sentinel).
+struct HotVariant {
+    int K = 0;
+    bool via_slots = false;
+    int *col = nullptr;        // device [e_kept]
+    int *nodes = nullptr;      // device [K]: row index (node id, or exchange slot) of each hot source, by rank
+    int64_t hot_edges = 0;     // kept edges whose source is hot
+};
+
 struct Relation {
     int64_t e_in = 0;       // COO edges handed over
     int64_t e_kept = 0;     // after self-loop removal (if the plan does that)
@@ -100,6 +111,7 @@ struct Relation {
     int *need_rows = nullptr;                          // device: rows whose level-0 transform this rank computes
     int64_t n_need = 0;
     unsigned long long need_hash = 0;                  // FNV-1a of need_rows (equal lists -> one shared transform job)
+    std::vector<HotVariant> hot;                       // built lazily, one per (K, col / col_slot)
 };
 
 }  // namespace pea
@@ -120,6 +132,11 @@ namespace pea {
 
 int ensure_dinv(pea_plan *plan, int rel, bool from_col, hipStream_t stream);
 int ensure_dinv_slots(pea_plan *plan, int rel, bool from_col, hipStream_t stream);
+// hot-source variant of relation `rel` for an LDS image of K rows (nullptr in *out when the relation is too small or its
+// K most frequent sources carry too few of its edges to pay for the image)
+int ensure_hot(pea_plan *plan, int rel, int K, bool via_slots, hipStream_t stream, const HotVariant **out);
+constexpr int64_t kHotMinEdges = 1000000;   // relations below this never get an LDS image
+constexpr double kHotMinFraction = 0.15;    // ... nor those whose top-K sources carry less than this share of the edges
 
 // ---------------------------------------------------------------- aggregation (agg.hip)
 // AGG_GAT_BWD_D / _S: the two gather passes of the GAT backward (agg.hip): D walks a destination row's in-edges
@@ -167,6 +184,11 @@ struct AggGroup {
     float *ksum;           // D: d a_dst out / S: d a_src out, one float per head, stride ld_k
     const float *da_dst;   // S: d a_dst of the row (from the D pass), stride ld_k
     int accum;             // AGG_MEAN: add the mean to the row already in `out` (SAGE inference schedule: root term)
+    // LDS-staged hot sources (long-row kernel only): hot_col replaces `col` there, hot_nodes[k] = row of `feat` held at
+    // image row k, hot_K rows; hot_frac = share of the relation's edges served from the image (bookkeeping)
+    const int *hot_col, *hot_nodes;
+    int hot_K;
+    double hot_frac;
     const unsigned char *row_active;  // optional [N]: 0 = the row's output gradient is exactly zero (D: row, S: gathered row)
     int ld_g, ld_side, ld_k;
 };

@@ -193,7 +193,14 @@ __global__ __launch_bounds__(256) void predict_kernel(int64_t B, int R, int64_t 
         atomicOr(err, 1);
         return;
     }
-    pred[b] = mlp_score(repr + u * R, repr + i * R, R, w1, b1, w2, fc2_b[0]);
+    if (R == 16) {
+        float4 ur[4], ir[4];
+        load_row<4>(repr + u * R, ur);
+        load_row<4>(repr + i * R, ir);
+        pred[b] = mlp_score_reg<4>(ur, ir, w1, b1, w2, fc2_b[0]);
+    } else {
+        pred[b] = mlp_score(repr + u * R, repr + i * R, R, w1, b1, w2, fc2_b[0]);
+    }
 }
 
 // one wave per user: lanes score candidates, then rank / auc / loss by wave reductions
@@ -215,6 +222,8 @@ __global__ __launch_bounds__(256) void rank_kernel(int64_t U, int C, int R, int6
     float pos = 0.f;
     int higher = 0, gt = 0;
     float lsum = 0.f;
+    float4 ur[4];
+    if (R == 16) load_row<4>(repr + u * R, ur);   // the reference's repr_dim: the user's row stays in registers
     for (int base = 0; base < C; base += kWave) {
         const int c = base + lane;
         float sc = 0.f;
@@ -225,7 +234,13 @@ __global__ __launch_bounds__(256) void rank_kernel(int64_t U, int C, int R, int6
                 atomicOr(err, 1);
                 ok = false;
             } else {
-                sc = mlp_score(repr + u * R, repr + i * R, R, w1, b1, w2, fc2_b[0]);
+                if (R == 16) {   // same arithmetic, same order as mlp_score (rows held in registers)
+                    float4 ir[4];
+                    load_row<4>(repr + i * R, ir);
+                    sc = mlp_score_reg<4>(ur, ir, w1, b1, w2, fc2_b[0]);
+                } else {
+                    sc = mlp_score(repr + u * R, repr + i * R, R, w1, b1, w2, fc2_b[0]);
+                }
                 if (scores) scores[uidx * C + c] = sc;
             }
         }

@@ -16,6 +16,7 @@
 //   SAGE    : M_s [N, ...] neighbour means of the level's input, O_s [N, sum F]
 //   X [N, P*R]: last-layer outputs of every channel (the "stack" the fusion reads).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "model.h"
@@ -131,7 +132,9 @@ int build_schedule(pea_model *m) {
             u.o_col = x_cols;
             m->x_col.c[u.p] = x_cols;
             x_cols += u.HF;
-            PEA_REQUIRE(m->single_conv || u.HF == d.repr_dim, PEA_ERR_ARG,
+            // (a model of ONE channel has nothing to stack: its X is simply heads * repr_dim wide -- the autograd path of
+            // the per-layer conv drop-ins builds such models, nn/conv.py)
+            PEA_REQUIRE(m->single_conv || P == 1 || u.HF == d.repr_dim, PEA_ERR_ARG,
                         "model: channel %d ends %d columns wide but repr_dim is %d (a 1-step GAT channel with "
                         "num_heads > 1 cannot be stacked; the reference fails at models/base.py:196 too)",
                         u.p, u.HF, d.repr_dim);
@@ -540,6 +543,22 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                     if (via_slots) {
                         PEA_TRY(ensure_dinv_slots(plan, g.rel, fc, stream));
                         a.dinv = fc ? R.dinv_col_slot : R.dinv_row_slot;
+                    }
+                }
+            }
+            // LDS image of the relation's most frequent sources for the long-row kernel (item popularity is Zipf-like:
+            // a few hundred item rows serve a large share of the item -> user messages).  PEA_HOT=0 switches it off.
+            {
+                static const bool hot_on = !(getenv("PEA_HOT") && atoi(getenv("PEA_HOT")) == 0);
+                if (hot_on && R.n_long > 0 && a.W >= 16) {
+                    const int K = std::min(1024, (160 * 1024 - 2048) / (4 * a.W + 4)) & ~7;
+                    const HotVariant *hv = nullptr;
+                    PEA_TRY(ensure_hot(plan, g.rel, K, via_slots, stream, &hv));
+                    if (hv) {
+                        a.hot_col = hv->col;
+                        a.hot_nodes = hv->nodes;
+                        a.hot_K = hv->K;
+                        a.hot_frac = R.e_kept > 0 ? (double)hv->hot_edges / (double)R.e_kept : 0.0;
                     }
                 }
             }

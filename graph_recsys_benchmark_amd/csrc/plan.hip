@@ -399,7 +399,23 @@ __global__ void scatter_to_slots(int64_t N, const int *__restrict__ slot_of_node
     if (s >= 0) dst[s] = src[v];
 }
 
+__global__ void count_ids(int64_t E, const int *__restrict__ col, int *__restrict__ cnt) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&cnt[col[e]], 1);
+}
+
+__global__ void encode_hot(int64_t E, const int *__restrict__ col, const int *__restrict__ rank_of, int *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int j = col[e], r = rank_of[j];
+    out[e] = r >= 0 ? -(r + 2) : j;
+}
+
 void free_relation(Relation &R) {
+    for (HotVariant &h : R.hot) {
+        (void)hipFree(h.col);
+        (void)hipFree(h.nodes);
+    }
     (void)hipFree(R.col_slot); (void)hipFree(R.dinv_row_slot); (void)hipFree(R.dinv_col_slot);
     (void)hipFree(R.slot_of_node); (void)hipFree(R.need_rows);
     (void)hipFree(R.rowptr); (void)hipFree(R.col); (void)hipFree(R.dinv_row); (void)hipFree(R.dinv_col); (void)hipFree(R.invdeg); (void)hipFree(R.eid);
@@ -428,6 +444,81 @@ int ensure_dinv(pea_plan *plan, int rel, bool from_col, hipStream_t stream) {
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(cnt);
     PEA_REQUIRE(e == hipSuccess, PEA_ERR_HIP, "gcn norm: %s", hipGetErrorString(e));
+    return PEA_OK;
+}
+
+int ensure_hot(pea_plan *plan, int rel, int K, bool via_slots, hipStream_t stream, const HotVariant **out) {
+    *out = nullptr;
+    Relation &R = plan->rels[(size_t)rel];
+    const char *env = getenv("PEA_HOT_MIN_EDGES");
+    const int64_t min_edges = env ? atoll(env) : kHotMinEdges;
+    if (K < 8 || R.e_kept < min_edges) return PEA_OK;
+    for (const HotVariant &h : R.hot)
+        if (h.K == K && h.via_slots == via_slots) {
+            if (h.col) *out = &h;
+            return PEA_OK;
+        }
+    const int *col = via_slots ? R.col_slot : R.col;
+    PEA_REQUIRE(col != nullptr, PEA_ERR_ARG, "relation %d has no exchange layout (pea_plan_set_sources)", rel);
+    const int64_t n_ids = via_slots ? std::max<int64_t>(R.slots_per_rank * plan->shard_world, 1) : plan->N;
+    HotVariant hv;
+    hv.K = K;
+    hv.via_slots = via_slots;
+    int *cnt = nullptr;
+    PEA_HIP(hipMalloc((void **)&cnt, (size_t)n_ids * sizeof(int)));
+    std::vector<int> h_cnt((size_t)n_ids);
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)n_ids * sizeof(int), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(count_ids, dim3((unsigned)((R.e_kept + 255) / 256)), dim3(256), 0, stream, R.e_kept, col, cnt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), cnt, (size_t)n_ids * sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        (void)hipFree(cnt);
+        PEA_REQUIRE(false, PEA_ERR_HIP, "hot sources: %s", hipGetErrorString(e));
+    }
+    // the K most frequent sources (ties: smaller id first, so the choice is deterministic)
+    std::vector<int> ids((size_t)n_ids);
+    for (int64_t i = 0; i < n_ids; ++i) ids[(size_t)i] = (int)i;
+    const size_t k = (size_t)std::min<int64_t>(K, n_ids);
+    std::partial_sort(ids.begin(), ids.begin() + (ptrdiff_t)k, ids.end(), [&](int a, int b) {
+        return h_cnt[(size_t)a] != h_cnt[(size_t)b] ? h_cnt[(size_t)a] > h_cnt[(size_t)b] : a < b;
+    });
+    std::vector<int> nodes((size_t)K, ids[0]), rank_of((size_t)n_ids, -1);
+    for (size_t r = 0; r < k; ++r) {
+        if (h_cnt[(size_t)ids[r]] == 0) break;  // fewer than K distinct sources
+        nodes[r] = ids[r];
+        rank_of[(size_t)ids[r]] = (int)r;
+        hv.hot_edges += h_cnt[(size_t)ids[r]];
+    }
+    const char *envf = getenv("PEA_HOT_MIN_FRACTION");
+    const double min_frac = envf ? atof(envf) : kHotMinFraction;
+    if ((double)hv.hot_edges >= min_frac * (double)R.e_kept) {
+        int *rank_dev = nullptr;
+        e = hipMalloc((void **)&rank_dev, (size_t)n_ids * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&hv.col, (size_t)R.e_kept * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&hv.nodes, (size_t)K * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpyAsync(rank_dev, rank_of.data(), (size_t)n_ids * sizeof(int), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hv.nodes, nodes.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(encode_hot, dim3((unsigned)((R.e_kept + 255) / 256)), dim3(256), 0, stream, R.e_kept, col, rank_dev, hv.col);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(rank_dev);
+        if (e != hipSuccess) {
+            (void)hipFree(hv.col);
+            (void)hipFree(hv.nodes);
+            (void)hipFree(cnt);
+            PEA_REQUIRE(false, PEA_ERR_HIP, "hot sources: %s", hipGetErrorString(e));
+        }
+    }
+    (void)hipFree(cnt);
+    R.hot.reserve(8);  // pointers into the vector are handed out: never reallocate (a handful of variants at most)
+    PEA_REQUIRE(R.hot.size() < 8, PEA_ERR_ARG, "relation %d: too many hot-source variants", rel);
+    R.hot.push_back(hv);
+    if (hv.col) *out = &R.hot.back();
     return PEA_OK;
 }
 

@@ -8,7 +8,12 @@ and calls at models/base.py:138-139, so the reference's checkpoints load with st
 
 These per-layer modules run ONE conv per call (plan cached per edge_index tensor).  The fast path for a whole
 PEA model is PEABaseRecsysModel.forward (models/base.py here), which hands all P x S layers to one schedule.
-Forward only for now: calling them with autograd enabled on parameters that require grad raises.
+
+Training (reference solvers.py:213-216 with the reference's OWN channel loop, models/base.py:134-140): with autograd
+enabled and any input requiring grad, forward() runs through _ConvFunction -- the HIP forward that keeps the softmax
+statistics (pea_model_forward_train on a one-channel, one-step schedule over a plan that also holds the reversed
+relation) and the HIP backward of autograd.backward_conv_stack (gradient gathers over the reversed relation, fixed-order
+weight / bias / attention-vector reductions): gradients of x and of every parameter.
 """
 import ctypes as C
 import weakref
@@ -35,11 +40,76 @@ def _plan_for(edge_index, num_nodes, self_loops):
     return plan
 
 
-def _check_no_grad(module):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(
-            'the HIP conv path is forward-only so far (backward is the next row of SURVEY.md section 8f); '
-            'call under torch.no_grad()')
+_train_plan_cache = {}
+
+
+def _train_plan_for(edge_index, num_nodes, self_loops):
+    """Like _plan_for, with the reversed relation planned too (the backward's gathers walk it)."""
+    key = (id(edge_index), edge_index._version, int(num_nodes), bool(self_loops))
+    hit = _train_plan_cache.get(key)
+    if hit is not None and hit[0]() is edge_index:
+        return hit[1]
+    plan = GraphPlan(num_nodes, [[edge_index]], self_loops, with_reverse=True)
+    ref = weakref.ref(edge_index, lambda _r, k=key: _train_plan_cache.pop(k, None))
+    _train_plan_cache[key] = (ref, plan)
+    return plan
+
+
+def _wants_grad(module, x):
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+class _ConvFunction(torch.autograd.Function):
+    """One conv layer, differentiable: forward and backward in HIP on a one-channel, one-step PEAEngine."""
+
+    @staticmethod
+    def forward(ctx, engine, x, width, *params):
+        from ..autograd import _Layout, _view
+        lay = getattr(engine, '_layout', None)
+        if lay is None:
+            lay = engine._layout = _Layout(engine)
+        engine.forward([tuple(params)], x, att=None, train=True, out=engine._scratch_out)
+        out = _view(engine._wsf, lay.off_x, engine.plan.num_nodes, lay.ld_x)[:, :width].clone()
+        ctx.engine, ctx.width = engine, width
+        ctx.save_for_backward(x, *[t for t in params if t is not None])
+        ctx.present = [t is not None for t in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from ..autograd import backward_conv_stack
+        saved = list(ctx.saved_tensors)
+        x, it = saved[0], iter(saved[1:])
+        params = tuple(next(it) if p else None for p in ctx.present)
+        n = x.shape[0]
+        with torch.no_grad():
+            # the forward's statistics live in the engine's workspace: one backward per forward, in order (a module
+            # called twice before backward -- weight sharing across calls -- would need a second workspace)
+            dx, grads = backward_conv_stack(ctx.engine, d_out.contiguous().view(n, 1, ctx.width), x, [params])
+        out = [None if t is None else g.reshape(t.shape) for t, g in zip(params, grads[0])]
+        return (None, dx, None, *out)
+
+
+def _train_engine(module, kind, plan, in_channels, out_channels, heads, **kw):
+    """One training engine per (module, plan): a single channel of a single step, mean 'fusion' (identity for P = 1)."""
+    from ..engine import PEAEngine
+    cache = module.__dict__.setdefault('_train_engines', {})
+    eng = cache.get(id(plan))
+    if eng is None or eng.plan is not plan:
+        eng = PEAEngine(plan, kind, [1], in_channels, out_channels, out_channels, heads=heads, channel_aggr='mean',
+                        enable_backward=True, **kw)
+        eng._scratch_out = torch.empty((plan.num_nodes, out_channels), dtype=torch.float32, device=plan.device)
+        cache.clear()                       # one live engine per module: its workspace holds [N, .] training buffers
+        cache[id(plan)] = eng
+    return eng
+
+
+def _autograd_x(x, in_channels):
+    if not x.is_cuda:
+        raise RuntimeError('the HIP conv path needs CUDA tensors (there is no CPU fallback)')
+    if x.dim() != 2 or x.shape[1] != in_channels or x.dtype != torch.float32:
+        raise ValueError('x must be float32 [N, %d], got %s %s' % (in_channels, x.dtype, tuple(x.shape)))
+    return x.contiguous()
 
 
 def _check_x(x, in_channels):
@@ -94,9 +164,21 @@ class GATConv(torch.nn.Module):
         zeros(self.bias)
 
     def forward(self, x, edge_index, relu=False):
-        _check_no_grad(self)
         if self.training and self.dropout > 0:
             raise NotImplementedError('attention dropout > 0 is not implemented (p = 0 in every reference script)')
+        if _wants_grad(self, x):
+            x = _autograd_x(x, self.in_channels)
+            plan = _train_plan_for(edge_index, x.shape[0], True)
+            eng = _train_engine(self, 'gat', plan, self.in_channels, self.out_channels, self.heads,
+                                negative_slope=float(self.negative_slope))
+            fused_bias = self.bias if self.concat else None
+            out = _ConvFunction.apply(eng, x, self.heads * self.out_channels, self.lin.weight, self.att_i, self.att_j,
+                                      fused_bias)
+            if not self.concat:
+                out = out.view(x.shape[0], self.heads, self.out_channels).mean(dim=1)
+                if self.bias is not None:
+                    out = out + self.bias
+            return torch.relu(out) if relu else out
         x = _check_x(x, self.in_channels)
         n = x.shape[0]
         plan = _plan_for(edge_index, n, True)
@@ -147,7 +229,12 @@ class GCNConv(torch.nn.Module):
         zeros(self.bias)
 
     def forward(self, x, edge_index, relu=False):
-        _check_no_grad(self)
+        if _wants_grad(self, x):
+            x = _autograd_x(x, self.in_channels)
+            plan = _train_plan_for(edge_index, x.shape[0], True)
+            eng = _train_engine(self, 'gcn', plan, self.in_channels, self.out_channels, 1, gcn_deg_from=self.gcn_deg_from)
+            out = _ConvFunction.apply(eng, x, self.out_channels, self.weight, self.bias)
+            return torch.relu(out) if relu else out
         x = _check_x(x, self.in_channels)
         n = x.shape[0]
         plan = _plan_for(edge_index, n, True)
@@ -180,7 +267,13 @@ class SAGEConv(torch.nn.Module):
         self.lin_root.reset_parameters()
 
     def forward(self, x, edge_index, relu=False):
-        _check_no_grad(self)
+        if _wants_grad(self, x):
+            x = _autograd_x(x, self.in_channels)
+            plan = _train_plan_for(edge_index, x.shape[0], False)
+            eng = _train_engine(self, 'sage', plan, self.in_channels, self.out_channels, 1)
+            out = _ConvFunction.apply(eng, x, self.out_channels, self.lin_rel.weight, self.lin_rel.bias,
+                                      self.lin_root.weight)
+            return torch.relu(out) if relu else out
         x = _check_x(x, self.in_channels)
         n = x.shape[0]
         plan = _plan_for(edge_index, n, False)

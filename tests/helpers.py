@@ -201,45 +201,7 @@ def oracle_params(model, steps, kind, heads=1):
     return sd, cps, hls
 
 
-def in_edges_of(edge_index, nodes):
-    """Columns of the int64 [2, E] COO whose destination is in `nodes` (original order kept)."""
-    mask = np.isin(edge_index[1], nodes)
-    return edge_index[:, mask]
-
-
-def f64_rows_two_step(kind, sd, p, rel1, rel2, rows, heads=1):
-    """float64 value of channel p's output at the destination rows `rows`, computed on the 2-hop in-neighbourhood only
-    ("parity spot-checked on sampled destination rows recomputed on CPU").  GAT and SAGE only:
-    their per-row result depends on the complete in-neighbourhood of the row and nothing else (GCN's 1.5.0 degree is
-    over the SOURCE index, i.e. global).  Returns [len(rows), R]."""
-    import torch
-    from oracle import pyg_restatement as R
-    assert kind in ('gat', 'sage')
-    rows = np.asarray(rows, dtype=np.int64)
-    e2 = in_edges_of(rel2, rows)
-    s1 = np.union1d(rows, e2[0])                              # rows whose layer-1 output is read
-    e1 = in_edges_of(rel1, s1)
-    s0 = np.union1d(s1, e1[0])                                # rows of x that are read
-    remap = -np.ones(int(max(s0.max(), rows.max())) + 1, dtype=np.int64)
-    remap[s0] = np.arange(s0.size)
-    x = torch.from_numpy(sd['x'][s0]).double()
-
-    def conv(step, h, ei, last):
-        pre = 'pea_channels.%d.gnn_layers.%d.' % (p, step)
-        lp = {k[len(pre):]: torch.from_numpy(v).double() for k, v in sd.items() if k.startswith(pre)}
-        if kind == 'gat':
-            hh = 1 if last else heads
-            c = R.GATConv(h.shape[1], lp['lin.weight'].shape[0] // hh, heads=hh)
-        else:
-            c = R.SAGEConv(h.shape[1], lp['lin_rel.weight'].shape[0])
-        c = c.double()
-        c.load_state_dict(lp, strict=True)
-        with torch.no_grad():
-            return c(h, torch.from_numpy(remap[ei]))
-
-    h1 = torch.relu(conv(0, x, e1, False))                    # exact on s1 (all their in-edges are present)
-    out = conv(1, h1, e2, True)                               # exact on rows
-    return out[torch.from_numpy(remap[rows])].numpy()
+from oracle.rows64 import f64_rows_two_step, in_edges_of  # noqa: E402,F401  (shared with bench.py)
 
 
 def assert_fused_close(got_fused, got_stack, want_fused, truth_fused, att, channel_aggr='att', rtol=1e-5, atol=1e-6, what='fused'):

@@ -97,3 +97,53 @@ def test_backward_matches_float64_autograd(kind, heads, aggr):
     with torch.no_grad():
         l2 = float(model.loss(torch.from_numpy(batch).cuda()))
     assert np.isfinite(l2)
+
+
+@pytest.mark.parametrize('kind,heads,aggr', [('gcn', 1, 'att'), ('sage', 1, 'att'), ('gat', 1, 'att'), ('gat', 2, 'mean')])
+def test_conv_dropins_train_through_the_reference_channel_loop(kind, heads, aggr):
+    """INTEGRATION.md's first switch: keep the reference's OWN model code (channel loop models/base.py:134-140, stack and
+    fusion :191-203, predict :208-214, loss :43-48 -- restated here with plain torch ops exactly as the reference writes
+    them) and only swap the conv classes.  loss.backward() then runs through the per-layer drop-ins' HIP backward;
+    gradients of every parameter against float64 autograd."""
+    n, blocks, rel = random_hin(43, n_user=1200, n_item=350, n_attr=25, e_u2i=16000, e_attr=1200)
+    u2i, a2i = rel['u2i'], rel['a2i']
+    flip = lambda e: np.ascontiguousarray(e[::-1])
+    edges = [[u2i, flip(u2i)], [a2i, flip(u2i)], [flip(a2i), a2i, flip(u2i)], [flip(u2i)]]
+    steps = [2, 2, 3, 1] if not (kind == 'gat' and heads > 1) else [2, 2, 3]   # a 1-step multi-head channel cannot be stacked
+    edges = edges[:len(steps)]
+    model = build_model(kind, n, edges, steps, 32, 32, 16, heads=heads, channel_aggr=aggr)
+    model.load_state_dict(random_state_dict(model, 9, scale=0.25))
+    rng = np.random.default_rng(4)
+    batch = np.stack([rng.integers(*blocks['u'], size=384), rng.integers(*blocks['i'], size=384),
+                      rng.integers(*blocks['i'], size=384)], axis=1).astype(np.int64)
+    bt = torch.from_numpy(batch).cuda()
+    model.train()
+    model.zero_grad()
+    # --- the reference's forward / predict / loss, line for line in torch ops, over the drop-in conv modules
+    x = [channel(model.x, eil).unsqueeze(1)                                   # PEABaseChannel.forward: relu between steps
+         for channel, eil in zip(model.pea_channels, model.meta_path_edge_index_list)]
+    x = torch.cat(x, dim=1)
+    if aggr == 'att':
+        atts = torch.softmax(torch.sum(x * model.att, dim=-1), dim=-1).unsqueeze(-1)
+        cached = torch.sum(x * atts, dim=1)
+    else:
+        cached = x.mean(dim=1)
+
+    def predict(u, i):
+        z = torch.cat([cached[u], cached[i]], dim=-1)
+        return model.fc2(torch.relu(model.fc1(z)))
+
+    loss = -(predict(bt[:, 0], bt[:, 1]) - predict(bt[:, 0], bt[:, 2])).sigmoid().log().sum()
+    loss.backward()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    want_loss, want = f64_loss_and_grads(kind, sd, edges, steps, heads, aggr, batch)
+    np.testing.assert_allclose(float(loss), want_loss, rtol=2e-5)
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        g, w = p.grad.detach().cpu().numpy().astype(np.float64), want[name]
+        scale = max(np.abs(w).max(), 1e-12)
+        err = np.abs(g - w).max()
+        assert err <= 2e-4 * scale + 1e-9, '%s: max err %.3e vs scale %.3e' % (name, err, scale)
+    # same loss as the whole-model schedule on the same parameters
+    with torch.no_grad():
+        np.testing.assert_allclose(float(model.loss(bt)), float(loss), rtol=2e-5)
