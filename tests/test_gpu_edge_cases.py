@@ -111,3 +111,53 @@ def test_graphed_forward_replays_the_same_result():
         want2 = eng.forward(params, x, att=att).clone()
         got2 = eng.forward_graphed(params, x, att=att)
         assert got2.data_ptr() == got.data_ptr() and torch.equal(got2, want2) and not torch.equal(want2, want)
+
+
+def _kernel_names_of_one_forward(model):
+    import ctypes as C
+    from graph_recsys_benchmark_amd import _lib
+    lib = _lib.load()
+    lib.pea_profile_enable(1)
+    with torch.no_grad():
+        model.forward()
+    torch.cuda.synchronize()
+    lib.pea_profile_enable(0)
+    cap = 4096
+    names, cnt = C.create_string_buffer(cap * 32), C.c_int()
+    lib.pea_profile_read(cap, names, None, None, C.byref(cnt))
+    return {names.raw[i * 32:(i + 1) * 32].split(b'\0')[0].decode() for i in range(cnt.value)}
+
+
+@pytest.mark.parametrize('kind', ['gat', 'gcn', 'sage'])
+def test_lds_staged_hot_sources_are_bitwise_the_plain_kernel(kind, monkeypatch):
+    """Relations whose few hottest sources carry a large share of the edges (Zipf item popularity) get those rows staged in
+    an LDS image by the long-row kernel (csrc/agg.hip: agg_long_hot_kernel).  Same edges, same order, same values: the
+    result must be BITWISE the plain kernel's (PEA_HOT=0), on a graph with hub rows, multi-edges and every row bin."""
+    from helpers import random_hin
+    monkeypatch.setenv('PEA_HOT_MIN_EDGES', '1000')
+    n, blocks, rel = random_hin(17, n_user=6000, n_item=500, n_attr=30, e_u2i=150000, e_attr=2500)
+    u2i, a2i = rel['u2i'], rel['a2i']
+    flip = lambda e: np.ascontiguousarray(e[::-1])
+    edges = [[u2i, flip(u2i)], [a2i, flip(u2i)], [flip(u2i), u2i], [flip(a2i), flip(u2i)]]
+    steps = [2, 2, 2, 2]
+    model = build_model(kind, n, edges, steps, 64, 64, 16)
+    model.load_state_dict(random_state_dict(model, 12))
+    model.eval()
+    monkeypatch.setenv('PEA_HOT', '1')
+    names = _kernel_names_of_one_forward(model)
+    assert any(nm.startswith('agg_longhot_') for nm in names), names       # the item -> user relation took the LDS path
+    with torch.no_grad():
+        hot_fused, hot_stack = model.forward(return_stack=True)
+    monkeypatch.setenv('PEA_HOT', '0')
+    assert not any(nm.startswith('agg_longhot_') for nm in _kernel_names_of_one_forward(model))
+    with torch.no_grad():
+        fused, stack = model.forward(return_stack=True)
+    assert torch.equal(hot_stack, stack) and torch.equal(hot_fused, fused)
+    # and both agree with the CPU oracle
+    sd = {k: _np(v) for k, v in model.state_dict().items()}
+    cps = [[{k[len('pea_channels.%d.gnn_layers.%d.' % (p, s)):]: v for k, v in sd.items()
+             if k.startswith('pea_channels.%d.gnn_layers.%d.' % (p, s))} for s in range(2)] for p in range(4)]
+    want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, [[1, 1]] * 4, att=sd.get('att'), return_stack=True)
+    t_fused, t_stack = f64_forward(kind, sd, edges, steps, 1, 'att')
+    assert_fp32_close(_np(hot_stack), wstack, t_stack, what='stack')
+    assert_fused_close(_np(hot_fused), _np(hot_stack), want, t_fused, sd.get('att'))
