@@ -547,10 +547,12 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 }
             }
             // LDS image of the relation's most frequent sources for the long-row kernel (item popularity is Zipf-like:
-            // a few hundred item rows serve a large share of the item -> user messages).  PEA_HOT=0 switches it off.
+            // a few hundred item rows serve a large share of the item -> user messages).  OFF unless PEA_HOT=1: measured
+            // slower than the plain kernel on the 25m-shaped graph, kept for the record
+            // and for graphs with heavier skew.
             {
                 const char *hot_env = getenv("PEA_HOT");   // read per forward: tests and A/B runs flip it inside one process
-                const bool hot_on = !(hot_env && atoi(hot_env) == 0);
+                const bool hot_on = hot_env && atoi(hot_env) != 0;
                 if (hot_on && R.n_long > 0 && a.W >= 16) {
                     const int K = std::min(1024, (160 * 1024 - 2048) / (4 * a.W + 4)) & ~7;
                     const HotVariant *hv = nullptr;

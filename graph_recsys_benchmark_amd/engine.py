@@ -391,6 +391,57 @@ def bpr_score(repr_, triples, fc1_w, fc1_b, fc2_w, fc2_b, want_preds=False, vali
     return (loss, pos, neg) if want_preds else loss
 
 
+class _EntityReg(torch.autograd.Function):
+    """reg(x) with the gradient rows of the same launch (csrc/entity.hip); backward = one index_add into dx."""
+
+    @staticmethod
+    def forward(ctx, x, batch9):
+        reg, rows = _entity_launch(x, batch9, want_grad=True)
+        ctx.save_for_backward(rows, batch9)
+        ctx.shape = x.shape
+        return reg
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, t = ctx.saved_tensors
+        ids = t[:, [1, 3, 4, 0, 6, 7]].reshape(-1)            # order of the six gradient rows per batch row
+        dx = torch.zeros(ctx.shape, dtype=rows.dtype, device=rows.device)
+        dx.index_add_(0, ids, rows * g)
+        return dx, None
+
+
+def _entity_launch(x, batch9, want_grad):
+    lib = _lib.require_device()
+    if batch9.dtype != torch.int64 or batch9.dim() != 2 or batch9.shape[1] < 9:
+        raise ValueError('entity-aware batches are int64 [B, 9] (u, i+, i-, 6 entity columns)')
+    if batch9.stride(1) != 1:
+        batch9 = batch9.contiguous()
+    xd = x.detach()
+    if xd.stride(1) != 1 or xd.stride(0) % 4:
+        xd = xd.contiguous()
+    b, f = batch9.shape[0], xd.shape[1]
+    ws_bytes = int(lib.pea_entity_reg_workspace_bytes(b, f))
+    if ws_bytes == 0:
+        raise ValueError('entity_reg: emb_dim %d must be a multiple of 4, <= 256' % f)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xd.device)
+    reg = torch.empty((), dtype=torch.float32, device=xd.device)
+    rows = torch.empty((6 * b, f), dtype=torch.float32, device=xd.device) if want_grad else None
+    _lib.check(lib.pea_entity_reg(b, f, xd.shape[0], _lib.ptr(xd), xd.stride(0), _lib.ptr(batch9), batch9.stride(0),
+                                  _lib.ptr(reg), _lib.ptr(rows), _lib.ptr(ws), ws_bytes, _lib.current_stream()))
+    if len(_pending_err) >= 64:
+        check_pending_errors()
+    _pending_err.append(ws[:4].view(torch.int32)[0])
+    return reg, rows
+
+
+def entity_reg(x, batch9):
+    """Entity-aware regulariser (reference models/base.py:50-73) in one HIP launch; differentiable with respect to x
+    when x requires grad (gradient rows come out of the same launch)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _EntityReg.apply(x, batch9)
+    return _entity_launch(x, batch9, want_grad=False)[0]
+
+
 def predict(repr_, unids, inids, fc1_w, fc1_b, fc2_w, fc2_b):
     """fc2(relu(fc1([repr[u] || repr[i]]))) -> [B, 1]  (reference models/base.py:208-214)."""
     lib = _lib.require_device()

