@@ -44,6 +44,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); 6290 G
 # LDS": 16.8-18.8 TB/s L2-resident, 8.6 TB/s from a 38 MB table in the Infinity Cache, 6.0-6.1 TB/s from HBM)
 GATHER_CEILING_GBS = {'l2': 18800.0, 'infinity_cache': 8600.0, 'hbm': 6100.0}
 L2_BYTES, MALL_BYTES = 32 << 20, 256 << 20   # aggregate L2 (8 x 4 MiB), Infinity Cache
+FP32_MFMA_PEAK_TF = 157.3                    # fp32-input MFMA = the fp32 vector rate (MI355X_MICROARCH.md, Matrix cores)
 
 
 def parse(argv=None):
@@ -183,29 +184,69 @@ def cpu_baseline(dataset, model, kind, samples):
 
 
 def load_traffic(preset, kind, scale, world):
-    """{kernel: {hbm_bytes_per_launch, l2_hit_rate, ...}} measured with rocprofv3 PMC passes for THIS preset / kind at
-    full scale on one GPU (profiles/traffic.json, written by profiles/summarize.py), or {}."""
-    if scale != 1.0 or world != 1:
+    """{kernel: {hbm_bytes_per_launch, l2_hit_rate, ...}} measured with rocprofv3 PMC passes for THIS preset / kind / scale
+    on one GPU (profiles/traffic.json, written by profiles/summarize.py; key '<preset>/<kind>' at full scale,
+    '<preset>@<scale>/<kind>' otherwise), or {}."""
+    if world != 1:
         return {}
+    key = '%s/%s' % (preset, kind) if scale == 1.0 else '%s@%g/%s' % (preset, scale, kind)
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            return json.load(f).get('%s/%s' % (preset, kind), {})
+            return json.load(f).get(key, {})
     except Exception:
         return {}
 
 
 def gather_tier(table_bytes, l2_hit_rate):
-    """Which cache tier serves the gathered rows: from the measured L2 hit rate when there is one (>= 0.5: the XCD L2s),
-    else from the table's footprint against the aggregate L2 / the Infinity Cache."""
+    """(tier name, ceiling in GB/s, how it was decided) of a row gather.  With a measured L2 hit rate h of the kernel:
+    h >= 0.5 -> the XCD L2s serve most rows: the guide's L2-resident ceiling; h < 0.5 -> mixed: the harmonic blend of the
+    L2 ceiling (share h) and the ceiling of where the misses go (Infinity Cache while the table fits its 256 MiB, else
+    HBM).  Without a PMC profile for this preset / kind: from the table's footprint alone."""
+    below = 'infinity_cache' if table_bytes <= MALL_BYTES else 'hbm'
     if l2_hit_rate is not None:
         if l2_hit_rate >= 0.5:
-            return 'l2', 'measured L2 hit rate %.2f' % l2_hit_rate
-        return ('infinity_cache' if table_bytes <= MALL_BYTES else 'hbm'), 'measured L2 hit rate %.2f, table %.0f MB' % (l2_hit_rate, table_bytes / 1e6)
+            return 'l2', GATHER_CEILING_GBS['l2'], 'measured L2 hit rate %.2f' % l2_hit_rate
+        blend = 1.0 / (l2_hit_rate / GATHER_CEILING_GBS['l2'] + (1.0 - l2_hit_rate) / GATHER_CEILING_GBS[below])
+        return 'l2+' + below, blend, ('measured L2 hit rate %.2f, table %.0f MB: harmonic blend of the L2 and %s gather '
+                                      'ceilings' % (l2_hit_rate, table_bytes / 1e6, below))
     if table_bytes <= L2_BYTES // 8:
-        return 'l2', 'table %.1f MB fits one XCD L2 (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
-    if table_bytes <= MALL_BYTES:
-        return 'infinity_cache', 'table %.0f MB fits the Infinity Cache (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
-    return 'hbm', 'table %.0f MB exceeds the Infinity Cache' % (table_bytes / 1e6)
+        return 'l2', GATHER_CEILING_GBS['l2'], 'table %.1f MB fits one XCD L2 (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
+    return below, GATHER_CEILING_GBS[below], 'table %.0f MB vs the 256 MiB Infinity Cache (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
+
+
+def kernel_roofline(name, rec, traffic_tab, flops):
+    """roofline object of one kernel from its live HIP-event record (+ the committed PMC figures of this workload)."""
+    launches, ms, units, pulled, table = rec
+    avg_s = ms / launches * 1e-3
+    meas = traffic_tab.get(name, {})
+    hit, traffic = meas.get('l2_hit_rate'), meas.get('hbm_bytes_per_launch')
+    out = {'kernel': name, 'launches': launches, 'avg_launch_ms': ms / launches}
+    if name in flops:                                        # dense transform: fp32 MFMA (exact fp32 products)
+        tf = flops[name] / (ms * 1e-3) / 1e12
+        out.update(bound='mfma', achieved=tf, peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s', frac=tf / FP32_MFMA_PEAK_TF,
+                   definition='2*rows*K*n_out flops of the launches / their time; peak = fp32-input MFMA '
+                              '(v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s, MI355X_MICROARCH.md)')
+    elif pulled > 0:                                         # neighbour aggregation: a row gather
+        tier, peak, why = gather_tier(table, hit)
+        achieved = pulled / launches / avg_s / 1e9
+        out.update(bound='hbm', achieved=achieved, peak=peak, unit='GB/s', frac=achieved / peak, tier=tier, tier_from=why,
+                   gather_table_bytes=table, gathered_bytes_per_launch=pulled / launches,
+                   definition='achieved = (4*W row bytes + 4 index bytes) x messages of the launch / avg launch time; peak '
+                              '= measured row-gather ceiling of the named cache tier (MI355X_MICROARCH.md, Indexed rows)')
+    else:                                                    # streaming kernels (fusion, scoring, packing)
+        achieved = units / launches / avg_s / 1e9
+        out.update(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                   definition='algorithmic bytes of the launch / avg launch time against the 8 TB/s HBM peak')
+    out.update(traffic=traffic,                              # fabric-side bytes per launch (rocprofv3 PMC) or null
+               traffic_GBs=None if not traffic else traffic / avg_s / 1e9,
+               traffic_frac_of_8TBs=None if not traffic else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
+               l2_hit_rate=hit, algorithmic_bytes_per_launch=units / launches,
+               algorithmic_GBs=units / launches / avg_s / 1e9)
+    return out
+
+
+def single_gpu_schedule(world, args):
+    return world == 1 and args.emulate_world <= 1
 
 
 def main():
@@ -344,29 +385,19 @@ def main():
         'reference_yardstick': {'algorithmic_bytes_per_step': alg_bytes, 'GBs': alg_bytes / step_s / 1e9},
     }
     if prof:
-        traffic_tab = load_traffic(args.preset, args.kind, args.scale, world if not args.emulate_world else args.emulate_world)
+        traffic_tab = {} if args.emulate_world else load_traffic(args.preset, args.kind, args.scale, world)
+        flops = {}
+        if args.kind in ('gat', 'gcn') and single_gpu_schedule(world, args):     # the two transform launches of a 2-step model
+            sp, n = dataset.spec, dataset.num_nodes
+            flops = {'gemm_mfma_shared': 2.0 * n * sp['emb_dim'] * sp['hidden_size'] * sp['num_metapaths'] * args.steps,
+                     'gemm_mfma_narrow': 2.0 * n * sp['hidden_size'] * sp['repr_dim'] * sp['num_metapaths'] * args.steps}
         dom = max(prof.items(), key=lambda kv: kv[1][1])
-        name, (launches, ms, units, pulled, table) = dom
-        avg_s = ms / launches * 1e-3
-        meas = traffic_tab.get(name, {})
-        hit = meas.get('l2_hit_rate')
-        tier, why = gather_tier(table, hit)
-        peak = GATHER_CEILING_GBS[tier] if pulled > 0 else HBM_PEAK_GBS
-        achieved = (pulled if pulled > 0 else units) / launches / avg_s / 1e9
-        traffic = meas.get('hbm_bytes_per_launch')
-        out['roofline'] = {
-            'bound': 'hbm', 'kernel': name, 'launches': launches, 'avg_launch_ms': ms / launches,
-            'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
-            'tier': tier, 'tier_from': why, 'gather_table_bytes': table,
-            'gathered_bytes_per_launch': pulled / launches,
-            'traffic': traffic,          # fabric-side bytes per launch (rocprofv3 PMC, this preset / kind) or null
-            'traffic_GBs': None if not traffic else traffic / avg_s / 1e9,
-            'traffic_frac_of_8TBs': None if not traffic else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
-            'l2_hit_rate': hit,
-            'algorithmic_bytes_per_launch': units / launches,      # SURVEY.md 8(d) yardstick share of this launch
-            'algorithmic_GBs': units / launches / avg_s / 1e9,
-            'definition': 'achieved = (4*W row bytes + 4 index bytes) x messages of the launch / avg launch time; peak = '
-                          'measured row-gather ceiling of the named cache tier (MI355X_MICROARCH.md, Indexed rows)'}
+        out['roofline'] = kernel_roofline(dom[0], dom[1], traffic_tab, flops)
+        gathers = {k: v for k, v in prof.items() if v[3] > 0}
+        if gathers:                                            # the dominant neighbour-aggregation kernel, when it is not
+            g = max(gathers.items(), key=lambda kv: kv[1][1])   # the dominant kernel overall (stress preset: the transform)
+            if g[0] != dom[0]:
+                out['roofline_gather'] = kernel_roofline(g[0], g[1], traffic_tab, flops)
         out['kernels_ms_per_step'] = {k: round(v[1] / args.steps, 4) for k, v in
                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}
     single = world == 1 and args.emulate_world <= 1

@@ -8,8 +8,8 @@ backward = per level, last to first:
              pea_model_backward_level  -- the sparse half in HIP: relu masks, bias / attention-vector gradient
                                           reductions, gradient gathers over the reversed relations (csrc/agg_bwd.hip)
              pea_grad_weight / pea_dense_batch on workspace views -- the dense half: dW = In^T dT (row-part MFMA
-                                          reduction, fixed order), dIn = dT W (forward transform kernels); only the
-                                          first layer's dx += dT_0 W stays a torch.mm
+                                          reduction, fixed order), dIn = dT W and the first layer's dx = dT_0 W_cat (one
+                                          deep-K job) on the forward transform kernels: no library GEMM in the step
 The fusion and the BPR scorer on top of `stack` are differentiated by torch autograd on the batch's rows only
 (models/base.py here: `_loss_autograd`), which is also what lets the last layer's gradient gathers skip every row outside
 the batch (StackOptions.read_ids).
@@ -75,7 +75,7 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
     for s_ in engine.steps:
         first.append(first[-1] + s_)
     grads = [[None] * len(slots) for _ in range(engine.n_layers)]
-    dx = torch.zeros_like(x)
+    dx = None                       # written whole by the level-0 input-gradient job(s)
     gpack = wsf[lay.off_gpack:lay.off_gpack + lay.pack_floats]
     # 1. gradient of the last-layer outputs, internal column order
     dX = _view(wsf, lay.off_dx, n, lay.ld_x)
@@ -109,24 +109,56 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
         if kind == 'sage':
             level_call(s, 0)
             dT.zero_()
-            for u in lv['units']:
+            units = lv['units']
+            pairs, jobs, root_jobs = [], [], []
+            shared = {}
+            for u in units:
+                shared[u['t_col']] = shared.get(u['t_col'], 0) + 1
+            for u in units:
                 li = first[u['p']] + u['s']
                 w_rel, _b, w_root = layer_params[li]
                 G = (dX if u['last'] else dO)[:, u['o_col']:u['o_col'] + u['HF']]
                 M = T[:, u['t_col']:u['t_col'] + u['in_w']]
                 In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]
-                grads[li][0], grads[li][2] = grad_weight([(G, M), (G, In)])
+                pairs += [(G, M), (G, In)]
                 grads[li][1] = _Slice(u['bias_off'], u['HF'])
-                dT[:, u['t_col']:u['t_col'] + u['in_w']] += G @ w_rel          # level 0: channels of one relation share M
-                direct = G @ w_root
-                if s == 0:
-                    dx += direct
+                if shared[u['t_col']] == 1:                                   # its own mean block: dM = G W_rel, written in place
+                    jobs.append((G, w_rel, dT[:, u['t_col']:u['t_col'] + u['in_w']]))
+                else:                                                         # level 0: channels of one relation share M
+                    tmp = torch.empty((n, u['in_w']), dtype=torch.float32, device=x.device)
+                    jobs.append((G, w_rel, tmp))
+                    shared.setdefault('acc', []).append((u, tmp))
+                if s > 0:
+                    root_jobs.append((G, w_root, dIn_all[:, u['in_col']:u['in_col'] + u['in_w']]))
+            dWs = grad_weight(pairs)
+            for q, u in enumerate(units):
+                li = first[u['p']] + u['s']
+                grads[li][0], grads[li][2] = dWs[2 * q], dWs[2 * q + 1]
+            if s == 0:
+                # dx = sum_u G_u W_root_u (+ the mean-path gradient below): one deep-K job when the G blocks are the
+                # contiguous columns of dO (every 2-step model), else one job per channel and a sum
+                cont = sorted((u for u in units if not u['last']), key=lambda u: u['o_col'])
+                ocols = sum(u['HF'] for u in cont)
+                contiguous = len(cont) == len(units) and all(
+                    cont[k]['o_col'] == sum(v['HF'] for v in cont[:k]) for k in range(len(cont)))
+                dx = torch.empty_like(x)
+                if contiguous:
+                    w_cat = torch.cat([layer_params[first[u['p']] + u['s']][2] for u in cont], dim=0)   # [ocols, emb]
+                    root_jobs.append((dO[:, :ocols], w_cat, dx))
                 else:
-                    dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] = direct
+                    parts = torch.empty((len(units),) + tuple(x.shape), dtype=torch.float32, device=x.device)
+                    for q, u in enumerate(units):
+                        G = (dX if u['last'] else dO)[:, u['o_col']:u['o_col'] + u['HF']]
+                        root_jobs.append((G, layer_params[first[u['p']] + u['s']][2], parts[q]))
+            dense_batch(jobs + root_jobs)
+            if s == 0 and not contiguous:
+                torch.sum(parts, dim=0, out=dx)
+            for u, tmp in shared.get('acc', []):
+                dT[:, u['t_col']:u['t_col'] + u['in_w']] += tmp
             level_call(s, 1)
             dagg = _view(wsf, lv['off_side'], n, lv['ld_t'])
             done = set()
-            for u in lv['units']:
+            for u in units:
                 if s == 0:
                     if u['t_col'] not in done:
                         dx += dagg[:, u['t_col']:u['t_col'] + u['in_w']]
@@ -140,14 +172,14 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
             # every first-layer channel reads x: one GEMM for all weight gradients, one for dx
             ncol = units[-1]['t_col'] + units[-1]['HF']
             dT0 = dT[:, :ncol]
+            dx = torch.empty_like(x)
             if kind == 'gat':
                 dW_all = grad_weight([(dT0, x)])[0]                         # [sum HF, emb]
                 w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=0)
-                dx += dT0 @ w_cat
             else:
                 dW_all = grad_weight([(x, dT0)])[0]                         # [emb, sum F]
-                w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=1)
-                dx += dT0 @ w_cat.t()
+                w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=1).t().contiguous()
+            dense_batch([(dT0, w_cat, dx)])                                 # dx = dT_0 W_cat: one deep-K job (K = sum HF)
         # weight gradients of the level in one launch pair, input gradients in one launch (dense_bwd.hip)
         if s > 0:
             pairs, dense = [], []

@@ -60,7 +60,8 @@ def main(root):
     return out
 
 
-BENCH_NAME = {'gemm_persist_k32': 'gemm_mfma_shared', 'gemm_skinny_k4': 'gemm_mfma_narrow'}   # names bench.py prints
+BENCH_NAME = {'gemm_persist_k32': 'gemm_mfma_shared', 'gemm_skinny_k4': 'gemm_mfma_narrow',   # names bench.py prints
+              'gemm_persist_k64': 'gemm_mfma_shared', 'gemm_skinny_k8': 'gemm_mfma_narrow'}
 
 
 def merge_traffic(res, key, source):
