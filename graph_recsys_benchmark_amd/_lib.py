@@ -68,6 +68,7 @@ SIGNATURES = {
     'pea_plan_set_sources': (_int, [_vp, _int, _vp, _i64, _vp, _i64, _vp]),
     'pea_model_num_stages': (_int, [_vp]),
     'pea_model_forward_stage': (_int, [_vp, _int, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
+    'pea_model_forward_stage_train': (_int, [_vp, _int, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
     'pea_model_num_exchanges': (_int, [_vp, _int]),
     'pea_model_exchange_desc': (_int, [_vp, _int, _int, C.POINTER(ExchangeDesc)]),
     'pea_model_forward_train': (_int, [_vp, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
@@ -85,6 +86,8 @@ SIGNATURES = {
     'pea_grad_weight_workspace_bytes': (_sz, []),
     'pea_grad_weight': (_int, [_i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_dense_batch': (_int, [_i64, _int, C.POINTER(DenseJob), _vp]),
+    'pea_grad_weight_sharded': (_int, [_i64, _int, _int, _int, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
+    'pea_dense_batch_rows': (_int, [_i64, _vp, _int, C.POINTER(DenseJob), _vp]),
     'pea_sample_negatives': (_int, [_i64, _int, _vp, _vp, _i64, _i64, _vp, _i64, C.c_uint64, C.c_uint32, _vp, _i64, _vp, _vp]),
     'pea_fuse': (_int, [_i64, _int, _int, _vp, _i64, C.POINTER(_int), _vp, _int, _int, _vp, _vp]),
     'pea_bpr_workspace_bytes': (_sz, [_i64]),

@@ -71,6 +71,18 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
         lay = engine._layout = _Layout(engine)
     kind, n, wsf = engine.kind, engine.plan.num_nodes, engine._wsf
     slots = PARAM_SLOTS[kind]
+    # sharded plan: every rank handles the rows it owns; gradient rows the gathers over a reversed relation read from
+    # other ranks are filled in between the two halves of a level (sharding.fill_in_*), the row-wise reductions give this
+    # rank's SHARE of the parameter gradients (summed over the ranks at the end), dx comes out row-sharded (all-gathered)
+    plan = engine.plan
+    sharded = engine.sharded
+    shard = plan.layout if sharded else None
+    shard3 = plan.shard if sharded else None
+    own32 = plan.own_rows_i32 if sharded else None
+    to_reduce = []
+
+    def rev_layout(rel):
+        return plan.source_layouts[plan.reverse_of[rel]]
     first = [0]
     for s_ in engine.steps:
         first.append(first[-1] + s_)
@@ -130,7 +142,8 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
                     shared.setdefault('acc', []).append((u, tmp))
                 if s > 0:
                     root_jobs.append((G, w_root, dIn_all[:, u['in_col']:u['in_col'] + u['in_w']]))
-            dWs = grad_weight(pairs)
+            dWs = grad_weight(pairs, shard=shard3)
+            to_reduce.extend(dWs)
             for q, u in enumerate(units):
                 li = first[u['p']] + u['s']
                 grads[li][0], grads[li][2] = dWs[2 * q], dWs[2 * q + 1]
@@ -150,11 +163,17 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
                     for q, u in enumerate(units):
                         G = (dX if u['last'] else dO)[:, u['o_col']:u['o_col'] + u['HF']]
                         root_jobs.append((G, layer_params[first[u['p']] + u['s']][2], parts[q]))
-            dense_batch(jobs + root_jobs)
+            dense_batch(jobs + root_jobs, rows=own32)
             if s == 0 and not contiguous:
                 torch.sum(parts, dim=0, out=dx)
             for u, tmp in shared.get('acc', []):
                 dT[:, u['t_col']:u['t_col'] + u['in_w']] += tmp
+            if sharded:     # the reverse mean aggregation gathers dM rows of the forward relation's destinations
+                seen = set()
+                for u in units:
+                    if u['t_col'] not in seen:
+                        seen.add(u['t_col'])
+                        shard.fill_in_rows(dT, u['t_col'], u['in_w'], rev_layout(u['rel']))
             level_call(s, 1)
             dagg = _view(wsf, lv['off_side'], n, lv['ld_t'])
             done = set()
@@ -168,18 +187,42 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
             continue
         level_call(s, 0)
         units = lv['units']
+        if sharded:
+            # runs of adjacent channels on one relation: their output-gradient columns (and GAT side records) travel together
+            side = _view(wsf, lv['off_side'], n, 4 * max(sum(u['heads'] for u in units), 1)) if kind == 'gat' else None
+            runs, a_k = [], 0
+            for u in units:
+                r = runs[-1] if runs else None
+                if r and r['rel'] == u['rel'] and r['last'] == u['last'] and r['col'] + r['w'] == u['o_col']:
+                    r['w'] += u['HF']
+                    r['heads'] += u['heads']
+                else:
+                    runs.append(dict(rel=u['rel'], last=u['last'], col=u['o_col'], w=u['HF'], a_k=a_k, heads=u['heads']))
+                a_k += u['heads']
+            for r in runs:
+                G = dX if r['last'] else dO
+                if r['last'] and active_ids is not None:       # only the batch's rows carry a gradient at the last layer
+                    shard.fill_in_ids(G, r['col'], r['w'], active_ids)
+                    if side is not None:
+                        shard.fill_in_ids(side, 4 * r['a_k'], 4 * r['heads'], active_ids)
+                else:
+                    shard.fill_in_rows(G, r['col'], r['w'], rev_layout(r['rel']))
+                    if side is not None:
+                        shard.fill_in_rows(side, 4 * r['a_k'], 4 * r['heads'], rev_layout(r['rel']))
+            level_call(s, 2)
         if s == 0:
             # every first-layer channel reads x: one GEMM for all weight gradients, one for dx
             ncol = units[-1]['t_col'] + units[-1]['HF']
             dT0 = dT[:, :ncol]
             dx = torch.empty_like(x)
             if kind == 'gat':
-                dW_all = grad_weight([(dT0, x)])[0]                         # [sum HF, emb]
+                dW_all = grad_weight([(dT0, x)], shard=shard3)[0]           # [sum HF, emb]
                 w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=0)
             else:
-                dW_all = grad_weight([(x, dT0)])[0]                         # [emb, sum F]
+                dW_all = grad_weight([(x, dT0)], shard=shard3)[0]           # [emb, sum F]
                 w_cat = torch.cat([layer_params[first[u['p']] + u['s']][0] for u in units], dim=1).t().contiguous()
-            dense_batch([(dT0, w_cat, dx)])                                 # dx = dT_0 W_cat: one deep-K job (K = sum HF)
+            to_reduce.append(dW_all)
+            dense_batch([(dT0, w_cat, dx)], rows=own32)                     # dx = dT_0 W_cat: one deep-K job (K = sum HF)
         # weight gradients of the level in one launch pair, input gradients in one launch (dense_bwd.hip)
         if s > 0:
             pairs, dense = [], []
@@ -194,8 +237,9 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
                 else:
                     pairs.append((In, dTu))                                     # [in, F]
                     dense.append((dTu, layer_params[li][0].t().contiguous(), dIn))
-            dWs = grad_weight(pairs)
-            dense_batch(dense)
+            dWs = grad_weight(pairs, shard=shard3)
+            to_reduce.extend(dWs)
+            dense_batch(dense, rows=own32)
         for q, u in enumerate(units):
             li = first[u['p']] + u['s']
             if kind == 'gat':
@@ -210,6 +254,9 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
     # the small (bias / attention-vector) gradients were reduced into the packed buffer level by level: one copy of it,
     # then views (the workspace itself is overwritten by the next step)
     packed = gpack.clone()
+    if sharded:
+        shard.all_reduce_sum_(to_reduce + [packed])      # the ranks' shares of every parameter gradient, one collective
+        shard.allgather_rows(dx)                         # dx rows are complete on their owners
     for g in grads:
         for q, item in enumerate(g):
             if isinstance(item, _Slice):
@@ -240,8 +287,10 @@ class PEAStackFunction(torch.autograd.Function):
         att = options.fuse_att
         if att is None:
             att = torch.zeros(engine.P, engine.repr_dim, device=x.device)
+        # sharded: each rank keeps the rows it owns (fused table and stack are defined there only); the caller exchanges
+        # the rows it reads (models/base.py: _loss_autograd)
         options.fused, stack = engine.forward(layer_params, x, att=att, masked=options.fuse_masked, want_stack=True,
-                                              train=True)
+                                              train=True, gather=False)
         ctx.engine, ctx.n_slots = engine, n_slots
         ctx.active_ids, ctx.active_rows = options.read_ids, None
         if options.read_ids is not None and engine.kind == 'gat':

@@ -380,12 +380,12 @@ int launch_bwd_mode(const AggLaunch &base, hipStream_t stream) {
 // out[c] = sum_n A[n, c] * (S ? S[n, c / F] : 1) for c < W, rows in a fixed order (two stages, no atomics).
 // Stage 1: block b owns a contiguous row chunk; its 256 threads are 4 row lanes x 64 columns (256-byte coalesced
 // row pieces), partial sums of the 4 row lanes are folded through LDS in lane order.
-__global__ __launch_bounds__(256) void colsum_stage1(int64_t N, int W, int F, const float *__restrict__ A, int lda,
+__global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int F, const float *__restrict__ A, int lda,
                                                      const float *__restrict__ S, int lds, float *__restrict__ part) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(N, r0 + rows_per);
+    const int64_t rows_per = (M.n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(M.n, r0 + rows_per);
     for (int c0 = 0; c0 < W; c0 += 64) {
         const int c = c0 + cl;
         float s = 0.f;
@@ -397,11 +397,14 @@ __global__ __launch_bounds__(256) void colsum_stage1(int64_t N, int W, int F, co
             for (; r + 28 < r1; r += 32) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = r + 4 * u;
-                    acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
+                    const int64_t rr = M.row(r + 4 * u);   // sharded plans: the q-th own row (rows past N: a short last tile)
+                    if (rr < M.N) acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
                 }
             }
-            for (; r < r1; r += 4) acc[0] += A[r * lda + c] * (S ? S[r * lds + k] : 1.f);
+            for (; r < r1; r += 4) {
+                const int64_t rr = M.row(r);
+                if (rr < M.N) acc[0] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
+            }
             s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         }
         red[rl][cl] = s;
@@ -431,11 +434,12 @@ __global__ __launch_bounds__(256) void colsum_stage2(int nparts, int W, const fl
 }
 
 // in place: G[n, c] = O[n, c] > 0 ? G[n, c] : 0   (relu between steps, reference models/base.py:138)
-__global__ __launch_bounds__(256) void relu_mask_kernel(int64_t N, int W4, float *__restrict__ G, int ldg,
+__global__ __launch_bounds__(256) void relu_mask_kernel(const RowMap M, int W4, float *__restrict__ G, int ldg,
                                                         const float *__restrict__ O, int ldo) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= N * W4) return;
-    const int64_t r = idx / W4;
+    if (idx >= M.n * W4) return;
+    const int64_t r = M.row(idx / W4);
+    if (r >= M.N) return;
     const int c = (int)(idx % W4) * 4;
     float4 g = ld4(G + r * ldg + c);
     const float4 o = ld4(O + r * ldo + c);
@@ -456,21 +460,21 @@ int launch_gat_backward(AggMode mode, const AggGroup *groups, int n_groups, hipS
     return mode == AGG_GAT_BWD_D ? launch_bwd_mode<AGG_GAT_BWD_D>(base, stream) : launch_bwd_mode<AGG_GAT_BWD_S>(base, stream);
 }
 
-int launch_colsum(int64_t N, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
+int launch_colsum(const RowMap &rows, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
                   float *out, hipStream_t stream) {
     if (W <= 0) return PEA_OK;
     ProfScope ps("colsum", stream, 0.0);
-    hipLaunchKernelGGL(colsum_stage1, dim3(kColsumParts), dim3(256), 0, stream, N, W, F, A, lda, S, lds, part);
+    hipLaunchKernelGGL(colsum_stage1, dim3(kColsumParts), dim3(256), 0, stream, rows, W, F, A, lda, S, lds, part);
     hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W, part, scale, out);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
 
-int launch_relu_mask(int64_t N, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream) {
-    if (W <= 0 || N <= 0) return PEA_OK;
+int launch_relu_mask(const RowMap &rows, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream) {
+    if (W <= 0 || rows.n <= 0) return PEA_OK;
     ProfScope ps("relu_mask", stream, 0.0);
-    const int64_t total = N * (W / 4);
-    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, N, W / 4, G, ldg, O, ldo);
+    const int64_t total = rows.n * (W / 4);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rows, W / 4, G, ldg, O, ldo);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }

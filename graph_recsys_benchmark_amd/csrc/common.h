@@ -193,15 +193,43 @@ struct AggGroup {
     int ld_g, ld_side, ld_k;
 };
 
+// Rows a rank owns under tile-interleaved ownership, as arithmetic: the q-th own row is
+//   row(q) = ((q / tile) * world + rank) * tile + q % tile        (q in [0, n): n = own tiles * tile; rows >= N are skipped)
+// world == 1: row(q) = q.  The row-wise reductions of the backward (column sums, weight gradients, relu masks) walk
+// q instead of all N rows when the plan is sharded.
+struct RowMap {
+    int tile = 1, world = 1, rank = 0;
+    int64_t n = 0;   // number of q values
+    int64_t N = 0;   // rows of the tables
+    __host__ __device__ int64_t row(int64_t q) const {
+        return world == 1 ? q : ((q / tile) * world + rank) * tile + q % tile;
+    }
+};
+inline RowMap make_rowmap(int64_t N, int tile, int world, int rank) {
+    RowMap m;
+    m.N = N;
+    if (world <= 1) {
+        m.n = N;
+        return m;
+    }
+    m.tile = tile;
+    m.world = world;
+    m.rank = rank;
+    const int64_t tiles = (N + tile - 1) / tile;                       // all tiles
+    const int64_t own_tiles = tiles > rank ? (tiles - rank + world - 1) / world : 0;
+    m.n = own_tiles * tile;
+    return m;
+}
+
 constexpr int kMaxAggGroups = 16;
 int launch_aggregate(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream);
 size_t partial_record_floats(int W, int F);
 // backward helpers (agg_bwd.hip)
 constexpr int kColsumParts = 512;
 int launch_gat_backward(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream);
-int launch_colsum(int64_t N, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
+int launch_colsum(const RowMap &rows, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
                   float *out, hipStream_t stream);
-int launch_relu_mask(int64_t N, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream);
+int launch_relu_mask(const RowMap &rows, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream);
 
 // ---------------------------------------------------------------- dense transform (gemm.hip)
 struct GemmSegment {   // output columns [c0, c1) of the job go to dst[row*ld + (c - c0)]

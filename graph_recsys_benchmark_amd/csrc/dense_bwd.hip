@@ -33,7 +33,8 @@ struct GwBatch {
 
 // stage 1: partial[job][part][MT*NT tiles][256] = sum over the part's rows of a[n][i] * b[n][j]
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, int64_t n_rows, float *__restrict__ partial) {
+__global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
+    const int64_t n_rows = M.n;   // sharded plans reduce over the rows this rank owns (RowMap), else over all rows
     __shared__ float red[3][MT * NT * 256];
     const GwJob &J = Jb.j[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
@@ -55,8 +56,9 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, int64_t n_row
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t n = n0 + 16 * u + kq;
-            const bool ok = n < r1;
-            const int64_t nc = ok ? n : r0;
+            const int64_t nr = M.row(n < r1 ? n : r0);
+            const bool ok = n < r1 && nr < M.N;
+            const int64_t nc = ok ? nr : 0;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[u][mt] = (ok && am[mt]) ? J.a[nc * J.lda + 16 * mt + i] : 0.f;
 #pragma unroll
@@ -110,10 +112,10 @@ __global__ __launch_bounds__(256) void gw_stage2(const GwBatch Jb, const float *
 }
 
 template <int MT, int NT>
-int launch_gw(const GwBatch &Jb, int64_t n_rows, float *partial, double bytes, hipStream_t stream) {
+int launch_gw(const GwBatch &Jb, const RowMap &rows, float *partial, double bytes, hipStream_t stream) {
     {
         ProfScope ps("grad_weight", stream, bytes);
-        hipLaunchKernelGGL((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, n_rows, partial);
+        hipLaunchKernelGGL((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
         PEA_HIP(hipGetLastError());
     }
     ProfScope ps("grad_weight_sum", stream);
@@ -133,9 +135,22 @@ extern "C" size_t pea_grad_weight_workspace_bytes(void) {
     return (size_t)kGwMaxJobs * kGwParts * 16 * 256 * sizeof(float) + 256;
 }
 
+extern "C" int pea_grad_weight_sharded(int64_t n_rows, int shard_tile, int shard_world, int shard_rank, int n_jobs,
+                                       const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace,
                                size_t workspace_bytes, void *stream) {
+    return pea_grad_weight_sharded(n_rows, 1, 1, 0, n_jobs, jobs_host, workspace, workspace_bytes, stream);
+}
+
+// the same reduction over the rows ONE RANK owns (row i belongs to rank (i / tile) % world): its share of dW; the
+// ranks' shares are summed by the host mirror (all-reduce)
+extern "C" int pea_grad_weight_sharded(int64_t n_rows, int shard_tile, int shard_world, int shard_rank, int n_jobs,
+                                       const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream) {
     PEA_REQUIRE(n_rows >= 0 && n_jobs >= 0 && (jobs_host || n_jobs == 0), PEA_ERR_ARG, "grad_weight: bad arguments");
+    PEA_REQUIRE(shard_world >= 1 && shard_rank >= 0 && shard_rank < shard_world && shard_tile > 0, PEA_ERR_ARG,
+                "grad_weight: bad shard (rank %d of %d, tile %d)", shard_rank, shard_world, shard_tile);
+    const RowMap rowmap = make_rowmap(n_rows, shard_tile, shard_world, shard_rank);
     PEA_REQUIRE(workspace && workspace_bytes >= pea_grad_weight_workspace_bytes(), PEA_ERR_NOMEM, "grad_weight: workspace too small");
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
     // cut every job into <= 64 x 64 blocks, group the blocks by tile shape, one pair of launches per shape and batch
@@ -173,15 +188,15 @@ extern "C" int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *job
                 hipStream_t st = (hipStream_t)stream;
                 int rc = PEA_OK;
                 switch (a * 3 + b) {
-                    case 0: rc = launch_gw<1, 1>(Jb, n_rows, partial, bytes, st); break;
-                    case 1: rc = launch_gw<1, 2>(Jb, n_rows, partial, bytes, st); break;
-                    case 2: rc = launch_gw<1, 4>(Jb, n_rows, partial, bytes, st); break;
-                    case 3: rc = launch_gw<2, 1>(Jb, n_rows, partial, bytes, st); break;
-                    case 4: rc = launch_gw<2, 2>(Jb, n_rows, partial, bytes, st); break;
-                    case 5: rc = launch_gw<2, 4>(Jb, n_rows, partial, bytes, st); break;
-                    case 6: rc = launch_gw<4, 1>(Jb, n_rows, partial, bytes, st); break;
-                    case 7: rc = launch_gw<4, 2>(Jb, n_rows, partial, bytes, st); break;
-                    default: rc = launch_gw<4, 4>(Jb, n_rows, partial, bytes, st); break;
+                    case 0: rc = launch_gw<1, 1>(Jb, rowmap, partial, bytes, st); break;
+                    case 1: rc = launch_gw<1, 2>(Jb, rowmap, partial, bytes, st); break;
+                    case 2: rc = launch_gw<1, 4>(Jb, rowmap, partial, bytes, st); break;
+                    case 3: rc = launch_gw<2, 1>(Jb, rowmap, partial, bytes, st); break;
+                    case 4: rc = launch_gw<2, 2>(Jb, rowmap, partial, bytes, st); break;
+                    case 5: rc = launch_gw<2, 4>(Jb, rowmap, partial, bytes, st); break;
+                    case 6: rc = launch_gw<4, 1>(Jb, rowmap, partial, bytes, st); break;
+                    case 7: rc = launch_gw<4, 2>(Jb, rowmap, partial, bytes, st); break;
+                    default: rc = launch_gw<4, 4>(Jb, rowmap, partial, bytes, st); break;
                 }
                 PEA_TRY(rc);
             }
@@ -189,7 +204,16 @@ extern "C" int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *job
     return PEA_OK;
 }
 
+extern "C" int pea_dense_batch_rows(int64_t n_rows, const int32_t *rows, int n_jobs, const pea_dense_job *jobs_host,
+                                    void *stream);
+
 extern "C" int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *jobs_host, void *stream) {
+    return pea_dense_batch_rows(n_rows, nullptr, n_jobs, jobs_host, stream);
+}
+
+// rows != null: only the listed rows (device int32 [n_rows], e.g. the rows a rank owns) of every operand are read / written
+extern "C" int pea_dense_batch_rows(int64_t n_rows, const int32_t *rows, int n_jobs, const pea_dense_job *jobs_host,
+                                    void *stream) {
     PEA_REQUIRE(n_rows >= 0 && n_jobs >= 0 && (jobs_host || n_jobs == 0), PEA_ERR_ARG, "dense_batch: bad arguments");
     std::vector<GemmJob> jobs((size_t)n_jobs);
     for (int q = 0; q < n_jobs; ++q) {
@@ -212,5 +236,5 @@ extern "C" int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *
         J.seg[0].relu = 0;
         jobs[(size_t)q] = J;
     }
-    return launch_gemm_batch(jobs.data(), n_jobs, nullptr, n_rows, (hipStream_t)stream);
+    return launch_gemm_batch(jobs.data(), n_jobs, rows, n_rows, (hipStream_t)stream);
 }

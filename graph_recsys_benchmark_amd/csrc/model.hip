@@ -347,7 +347,6 @@ int init_model(pea_model *m, const pea_plan *plan, const pea_model_desc *desc) {
     m->reverse_of.clear();
     if (m->backward) {
         PEA_REQUIRE(desc->reverse_of != nullptr, PEA_ERR_ARG, "model: enable_backward needs reverse_of (relation -> reversed relation)");
-        PEA_REQUIRE(plan->shard_world == 1, PEA_ERR_ARG, "model: the backward pass is single-GPU for now");
         m->reverse_of.assign(desc->reverse_of, desc->reverse_of + plan->rels.size());
     }
     m->d.steps = nullptr;
@@ -849,6 +848,21 @@ extern "C" int pea_model_forward_stage(pea_model *model, int stage, const float 
     PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward_stage: masked channel %d", masked_channel);
     return model_forward(model, stage, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
                          out_stack, nullptr, 0, 0, (hipStream_t)stream, false);
+}
+
+// One stage of the TRAINING forward of a sharded model (keeps the softmax statistics and every level buffer the backward
+// reads; no edge-less-row shortcuts): same stage / exchange protocol as pea_model_forward_stage.
+extern "C" int pea_model_forward_stage_train(pea_model *model, int stage, const float *const *params_host, const float *x,
+                                             const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
+                                             float *out_repr, float *out_stack, void *stream) {
+    PEA_REQUIRE(model && params_host && x && workspace, PEA_ERR_ARG, "forward_stage_train: null argument");
+    PEA_REQUIRE(model->backward, PEA_ERR_ARG, "forward_stage_train: the model was created without enable_backward");
+    PEA_REQUIRE(stage >= 0 && stage < (int)model->levels.size(), PEA_ERR_ARG, "forward_stage_train: stage %d of %d", stage,
+                (int)model->levels.size());
+    PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(model), PEA_ERR_NOMEM, "forward_stage_train: workspace too small");
+    PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward_stage_train: masked channel %d", masked_channel);
+    return model_forward(model, stage, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
+                         out_stack, nullptr, 0, 0, (hipStream_t)stream, true);
 }
 
 extern "C" int pea_model_num_exchanges(const pea_model *model, int level) {

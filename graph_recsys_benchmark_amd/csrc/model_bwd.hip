@@ -65,11 +65,17 @@ extern "C" int pea_model_set_active_rows(pea_model *m, const unsigned char *row_
 
 // phase 0: relu masks + bias gradients (all kinds); GAT/GCN: the aggregation backward -> dT_s (+ att gradients)
 // phase 1: SAGE only: reverse mean aggregation of dM_s (written by the host into the dT_s region) -> side_s region
+// Sharded plans (one rank's rows): the gradient gathers over the REVERSED relation read output-gradient rows (and GAT
+// side records) of destination nodes other ranks own, so GAT/GCN phase 0 stops before them -- relu masks, GAT D pass,
+// bias / att_i reductions over own rows -- the host fills those rows in from their owners (sharding.fill_in_rows on
+// the node-indexed dX / dO_s / side_s buffers), and
+// phase 2 runs the rest: GAT S pass / GCN reverse aggregation -> dT_s on own rows, att_j reduction.  (SAGE: the host
+// fills in dM_s rows between phase 0 and phase 1.)  Every row-wise reduction walks the rank's own rows (RowMap).
 extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void *workspace, size_t workspace_bytes,
                                         void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PEA_REQUIRE(m && workspace && m->backward, PEA_ERR_ARG, "backward: model without enable_backward");
-    PEA_REQUIRE(level >= 0 && level < (int)m->levels.size() && (phase == 0 || phase == 1), PEA_ERR_ARG, "backward: level %d phase %d", level, phase);
+    PEA_REQUIRE(level >= 0 && level < (int)m->levels.size() && phase >= 0 && phase <= 2, PEA_ERR_ARG, "backward: level %d phase %d", level, phase);
     PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(m), PEA_ERR_NOMEM, "backward: workspace too small");
     float *wsf = aligned_ws(workspace);
     pea_plan *plan = const_cast<pea_plan *>(m->plan);
@@ -81,15 +87,18 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
     float *dT = wsf + L.off_dt, *dO = wsf + L.off_do, *dX = wsf + m->off_dx;
     float *partial = wsf + m->off_partial;
     const bool loops = plan->flags & PEA_PLAN_SELF_LOOPS;
+    const bool sharded = plan->shard_world > 1;
+    const RowMap own = make_rowmap(N, plan->shard_tile, plan->shard_world, plan->shard_rank);
 
     if (d.kind == PEA_KIND_SAGE) {
+        PEA_REQUIRE(phase <= 1, PEA_ERR_ARG, "backward: SAGE levels have phases 0 and 1");
         if (phase == 0) {
             for (const Unit &u : L.units) {
                 float *G = u.last ? dX + u.o_col : dO + u.o_col;
                 const float *Out = u.last ? X + u.o_col : O + u.o_col;
                 const int ldg = u.last ? m->ld_x : L.ld_o;
-                if (!u.last) PEA_TRY(launch_relu_mask(N, u.HF, G, ldg, Out, ldg, stream));
-                PEA_TRY(launch_colsum(N, u.HF, u.HF, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + u.bias_off, stream));
+                if (!u.last) PEA_TRY(launch_relu_mask(own, u.HF, G, ldg, Out, ldg, stream));
+                PEA_TRY(launch_colsum(own, u.HF, u.HF, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + u.bias_off, stream));
             }
             return PEA_OK;
         }
@@ -118,7 +127,10 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         return PEA_OK;
     }
 
-    PEA_REQUIRE(phase == 0, PEA_ERR_ARG, "backward: GAT/GCN levels have a single phase");
+    PEA_REQUIRE(phase == 0 || phase == 2, PEA_ERR_ARG, "backward: GAT/GCN levels have phases 0 and (sharded) 2");
+    PEA_REQUIRE(phase == 0 || sharded, PEA_ERR_ARG, "backward: phase 2 is the second half of a SHARDED level");
+    const bool part_a = phase == 0;               // masks, D pass, reductions over what own rows already hold
+    const bool part_b = phase == 2 || !sharded;   // gathers over the reversed relation, reductions of their results
     std::vector<AggGroup> gd, gsrc;
     for (const GroupPlan &g : L.groups) {
         const int rr = m->reverse_of[(size_t)g.rel];
@@ -129,7 +141,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         float *G = g.last ? dX + g.out_col : dO + g.out_col;
         const float *Out = g.last ? X + g.out_col : O + g.out_col;
         const int ldg = g.last ? m->ld_x : L.ld_o;
-        if (!g.last) PEA_TRY(launch_relu_mask(N, g.W, G, ldg, Out, ldg, stream));
+        if (!g.last && part_a) PEA_TRY(launch_relu_mask(own, g.W, G, ldg, Out, ldg, stream));
         AggGroup a{};
         a.W = g.W;
         a.F = g.F;
@@ -148,7 +160,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             a.dinv_self = a.dinv;
             a.out = dT + g.col;
             a.ld_out = L.ld_t;
-            PEA_TRY(launch_aggregate(AGG_GCN, &a, 1, stream));
+            if (part_b) PEA_TRY(launch_aggregate(AGG_GCN, &a, 1, stream));
             continue;
         }
         a.att_src = pack + L.att_src_off + g.col;
@@ -171,7 +183,13 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         D.ld_stats = L.ld_stats;
         D.side_out = wsf + L.off_side + 4 * g.a_k;
         D.ksum = wsf + L.off_dad + g.a_k;
-        PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, &D, 1, stream));
+        if (sharded && level > 0) {  // the gather sources of this level sit in the forward's exchange buffer (slot order)
+            PEA_REQUIRE(R.col_slot != nullptr && g.xch_ld > 0, PEA_ERR_ARG, "backward: relation %d has no exchange layout", g.rel);
+            D.col = R.col_slot;
+            D.feat = wsf + g.xch_off;
+            D.ld_feat = g.xch_ld;
+        }
+        if (part_a) PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, &D, 1, stream));
         // S pass: source rows = destination rows of the reversed relation, gathers g_i and the side records
         AggGroup S = a;
         fill_lists(S, Rr);
@@ -184,7 +202,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         S.ksum = wsf + L.off_das + g.a_k;
         S.out = dT + g.col;
         S.ld_out = L.ld_t;
-        PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, &S, 1, stream));
+        if (part_b) PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, &S, 1, stream));
     }
     // Gradient reductions, one launch per run of groups whose columns (and heads) are contiguous:
     //   d bias[c] = sum_n g[n, c];   d att_j[c] = sum_n d a_src[n, head(c)] T[n, c];   d att_i likewise with d a_dst
@@ -198,12 +216,14 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             W += L.groups[gj++].W;
         float *G = g0.last ? dX + g0.out_col : dO + g0.out_col;
         const int ldg = g0.last ? m->ld_x : L.ld_o;
-        PEA_TRY(launch_colsum(N, W, W, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + g0.bias_off, stream));
+        if (part_a) PEA_TRY(launch_colsum(own, W, W, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + g0.bias_off, stream));
         if (d.kind == PEA_KIND_GAT) {
-            PEA_TRY(launch_colsum(N, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_das + g0.a_k, L.ld_k, 1.0f, colsum_part,
-                                  gpack + L.att_src_off + g0.col, stream));
-            PEA_TRY(launch_colsum(N, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_dad + g0.a_k, L.ld_k, 1.0f, colsum_part,
-                                  gpack + L.att_dst_off + g0.col, stream));
+            if (part_b)
+                PEA_TRY(launch_colsum(own, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_das + g0.a_k, L.ld_k, 1.0f, colsum_part,
+                                      gpack + L.att_src_off + g0.col, stream));
+            if (part_a)
+                PEA_TRY(launch_colsum(own, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_dad + g0.a_k, L.ld_k, 1.0f, colsum_part,
+                                      gpack + L.att_dst_off + g0.col, stream));
         }
         gi = gj;
     }

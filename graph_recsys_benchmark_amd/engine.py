@@ -99,6 +99,7 @@ class GraphPlan:
         self.source_layouts = {}
         if self.shard[1] > 1:
             own = self.layout.owned_rows(self.device).to(torch.int32).contiguous()
+            self.own_rows_i32 = own
             _lib.check(lib.pea_plan_set_owned_rows(handle, _lib.ptr(own), own.numel(), _lib.current_stream()))
             lays = [self.layout.source_layout(ei) for ei in uniq]
             # relations with few source nodes (attribute -> item ...) share ONE first-layer row list: own rows + the
@@ -243,14 +244,13 @@ class PEAEngine:
             _lib.check(fn(self._h, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m, _lib.ptr(self._ws),
                           self.workspace_bytes, _lib.ptr(out), _lib.ptr(stack), _lib.current_stream()))
             return (out, stack) if want_stack else out
-        if train:
-            raise NotImplementedError('the backward pass is single-GPU for now')
-        # Sharded forward: stage k computes this rank's rows of level k (and the transform feeding level k+1); the
+        # Sharded forward (train=True: the training schedule, stage by stage, same exchanges): stage k computes this rank's rows of level k (and the transform feeding level k+1); the
         # gather sources of level k+1 are then all-gathered from their owners; after the last stage the fused rows
         # (not the per-metapath stack) are all-gathered: the fusion is row-local under row ownership.
         shard = self.plan.layout
+        stage_fn = lib.pea_model_forward_stage_train if train else lib.pea_model_forward_stage
         for k in range(self.n_stages):
-            _lib.check(lib.pea_model_forward_stage(self._h, k, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m,
+            _lib.check(stage_fn(self._h, k, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m,
                                                    _lib.ptr(self._ws), self.workspace_bytes, _lib.ptr(out),
                                                    _lib.ptr(stack), _lib.current_stream()))
             if k + 1 < self.n_stages:
@@ -299,9 +299,10 @@ def _rows2d(t):
 _gw_ws = {}
 
 
-def grad_weight(pairs):
+def grad_weight(pairs, shard=None):
     """[a_q^T b_q for (a_q, b_q) in pairs]: a_q [N, ma], b_q [N, nb] float32 views (row strides free) over the same N
-    rows -- the weight gradients of one level in one pair of launches (pea_grad_weight: fixed-order reduction)."""
+    rows -- the weight gradients of one level in one pair of launches (pea_grad_weight: fixed-order reduction).
+    shard = (rank, world, tile): this rank's SHARE (the sum over the rows it owns); the caller all-reduces."""
     lib = _lib.require_device()
     if not pairs:
         return []
@@ -320,13 +321,18 @@ def grad_weight(pairs):
     ws = _gw_ws.get(dev)
     if ws is None:
         ws = _gw_ws[dev] = torch.empty(int(lib.pea_grad_weight_workspace_bytes()), dtype=torch.uint8, device=dev)
-    _lib.check(lib.pea_grad_weight(n, len(pairs), jobs, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    if shard is not None and shard[1] > 1:
+        _lib.check(lib.pea_grad_weight_sharded(n, int(shard[2]), int(shard[1]), int(shard[0]), len(pairs), jobs, _lib.ptr(ws),
+                                               ws.numel(), _lib.current_stream()))
+    else:
+        _lib.check(lib.pea_grad_weight(n, len(pairs), jobs, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
     return outs
 
 
-def dense_batch(triples_):
+def dense_batch(triples_, rows=None):
     """out_q = a_q @ w_q for (a_q [N, k], w_q [k, n_out], out_q [N, n_out] view) in triples_: one launch (the input
-    gradients dIn = dT W of one level); k, n_out and a's row stride must be multiples of 4."""
+    gradients dIn = dT W of one level); k, n_out and a's row stride must be multiples of 4.  rows (int32 device tensor):
+    only those rows are computed (the rows a rank owns in a sharded training step)."""
     lib = _lib.require_device()
     if not triples_:
         return
@@ -341,7 +347,10 @@ def dense_batch(triples_):
             raise ValueError('dense_batch: shapes %s @ %s -> %s' % (tuple(a.shape), tuple(w.shape), tuple(out.shape)))
         jobs[q] = _lib.DenseJob(a.data_ptr(), a.stride(0), w.shape[0], w.data_ptr(), w.stride(0), w.shape[1],
                                 out.data_ptr(), out.stride(0))
-    _lib.check(lib.pea_dense_batch(n, len(triples_), jobs, _lib.current_stream()))
+    if rows is not None:
+        _lib.check(lib.pea_dense_batch_rows(rows.numel(), _lib.ptr(rows), len(triples_), jobs, _lib.current_stream()))
+    else:
+        _lib.check(lib.pea_dense_batch(n, len(triples_), jobs, _lib.current_stream()))
 
 
 _pending_err = []      # error flags of bpr_score calls that have not been read back yet (one int32 view each)

@@ -8,7 +8,10 @@ Differences, all on purpose:
   * forward() hands ALL channels and steps to one schedule (engine.PEAEngine) instead of looping in Python;
   * graph tensors must be on the GPU; there is no CPU fallback (parity checks use oracle/ from the tests);
   * with autograd enabled (training), the conv stack runs through autograd.PEAStackFunction (HIP forward AND
-    backward); the cheap fusion + scorer on top of it are plain differentiable torch ops.
+    backward); the cheap fusion + scorer on top of it are plain differentiable torch ops;
+  * model.shard(rank, world) (one process per GPU) shards forward, eval, loss AND the training step
+    (zero_grad -> loss -> backward -> step, reference solvers.py:213-216) by destination rows; parameter gradients
+    come out summed over the ranks, so every rank's optimizer takes the same step.
 """
 import torch
 from torch.nn import Parameter
@@ -66,6 +69,25 @@ class GraphRecsysModel(torch.nn.Module):
             else:
                 self.cached_repr = self.forward()
         return self
+
+
+class _ShardedRows(torch.autograd.Function):
+    """rows = table[ids] of a row-sharded [N, W] table: forward = the rows each rank owns summed over the ranks
+    (ShardLayout.gather_rows); backward = the (replicated) gradient of those rows scattered into the rows THIS rank owns."""
+
+    @staticmethod
+    def forward(ctx, table, ids, layout):
+        ctx.layout, ctx.shape = layout, table.shape
+        ctx.save_for_backward(ids)
+        return layout.gather_rows(table.detach(), ids)
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, = ctx.saved_tensors
+        mine = ctx.layout.owner(ids) == ctx.layout.rank
+        d = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        d.index_add_(0, ids[mine], g[mine])
+        return d, None, None
 
 
 class PEABaseChannel(torch.nn.Module):
@@ -148,11 +170,9 @@ class PEABaseRecsysModel(GraphRecsysModel):
                                            self_loops=self.kind in ('gat', 'gcn'), shard_rank=self._shard[0],
                                            shard_world=self._shard[1], shard_tile=self._shard[2],
                                            gather_row_bytes=4 * hidden * (heads if self.kind == 'gat' else 1),
-                                           with_reverse=single)       # reversed relations drive the backward gathers
+                                           with_reverse=True)         # reversed relations drive the backward gathers
         attr = '_train_engine' if train else '_engine'
         if getattr(self, attr) is None:
-            if train and not single:
-                raise NotImplementedError('the backward pass is single-GPU for now')
             setattr(self, attr, _engine.PEAEngine(self._plan, self.kind, self.meta_path_steps, emb, hidden, repr_dim,
                                                   heads=heads if self.kind == 'gat' else 1,
                                                   channel_aggr=self.channel_aggr, gcn_deg_from=self.gcn_deg_from,
@@ -184,6 +204,9 @@ class PEABaseRecsysModel(GraphRecsysModel):
     def _forward_autograd(self, metapath_idx, return_stack):
         """Differentiable forward: conv stack forward + backward in HIP, fusion (models/base.py:194-203) in torch ops."""
         eng = self._get_engine(train=True)
+        if eng.sharded:
+            raise NotImplementedError('a sharded model is differentiated through model.loss(batch) (the rows the loss '
+                                      'reads are exchanged there); forward() under autograd is single-GPU')
         flat = [t for lp in self._layer_params() for t in lp]
         stack = PEAStackFunction.apply(eng, self.x, eng.slots, None, *flat)
         out = self._fuse_torch(stack, metapath_idx)
@@ -212,9 +235,16 @@ class PEABaseRecsysModel(GraphRecsysModel):
         opts = StackOptions(fuse_att=self.att.detach().reshape(eng.P, eng.repr_dim) if self.channel_aggr == 'att' else None,
                             read_ids=ids)
         stack = PEAStackFunction.apply(eng, self.x, eng.slots, opts, *flat)
-        self.cached_repr, self._repr_partial = opts.fused, False
+        self.cached_repr, self._repr_partial = opts.fused, eng.sharded
         b = t.shape[0]
-        rows = self._fuse_torch(stack[ids]).view(b, 3, -1)
+        if eng.sharded:
+            # every rank holds the stack rows it owns: the batch's rows are summed from their owners (one all-reduce of
+            # [3B, P * R], exact: x + 0), the loss is then computed replicated, and its gradient flows back into the
+            # stack rows this rank owns only
+            picked = _ShardedRows.apply(stack.view(stack.shape[0], -1), ids, eng.plan.layout).view(-1, eng.P, eng.repr_dim)
+        else:
+            picked = stack[ids]
+        rows = self._fuse_torch(picked).view(b, 3, -1)
 
         def score(i):
             return self.fc2(torch.relu(self.fc1(torch.cat([rows[:, 0], rows[:, i]], dim=-1))))
@@ -227,7 +257,7 @@ class PEABaseRecsysModel(GraphRecsysModel):
         same value as the single-GPU loss.  cached_repr is completed lazily if predict() is called before eval()."""
         sharded = self._shard[1] > 1
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self.training and grad and not sharded and self.x.is_cuda:
+        if self.training and grad and self.x.is_cuda:
             cf_loss = self._loss_autograd(pos_neg_pair_t)
             if self.entity_aware:
                 return cf_loss + self.entity_aware_coff * self._entity_reg(pos_neg_pair_t, self.x)

@@ -72,6 +72,19 @@ class SourceLayout:
         self.own_nodes_i32 = self.own_nodes.to(torch.int32).contiguous()   # what the HIP pack kernel reads
         self.own_count = int(self.own_nodes.numel())
         self.need_rows = torch.unique(torch.cat([shard.owned_rows(src_nodes.device), src_nodes])).to(torch.int32)
+        # fill-in exchanges (sharded backward): the source rows OTHER ranks own, and their slots in the rank-major buffer
+        self.other_nodes = src_nodes[~mine]
+        self.other_nodes_i32 = self.other_nodes.to(torch.int32).contiguous()
+        self.other_slots = slots[~mine]
+        self.other_slots_i32 = self.other_slots.to(torch.int32).contiguous()
+        self._bufs = {}
+
+    def buffer(self, width, like):
+        """Cached rank-major exchange buffer [world * M, width] for rows of `like`'s dtype / device."""
+        key = (int(width), like.dtype, str(like.device))
+        if key not in self._bufs:
+            self._bufs[key] = torch.zeros((self.shard.world * self.slots_per_rank, int(width)), dtype=like.dtype, device=like.device)
+        return self._bufs[key]
 
 
 class ShardLayout:
@@ -168,6 +181,70 @@ class ShardLayout:
         if done is not None:
             done.record()
         return rows
+
+    def fill_in_rows(self, table, col, width, layout, group=None):
+        """table [N, ld]: columns [col, col + width) of the rows at layout.src_nodes -- every rank has written the ones it
+        owns; fills in the others' IN PLACE (pack own rows -> in-place all-gather -> unpack the other ranks' rows).  The
+        sharded backward uses it on the node-indexed gradient buffers: the gathers over a reversed relation read rows of
+        the forward relation's destinations, which their owners produced."""
+        m = layout.slots_per_rank
+        if self.world == 1 or m == 0:
+            return
+        buf = layout.buffer(width, table)
+        hip = table.is_cuda and table.dtype == torch.float32 and width % 4 == 0 and col % 4 == 0 and table.stride(1) == 1 \
+            and table.stride(0) % 4 == 0
+        if layout.own_count:
+            if hip:
+                lib = _hip()
+                lib.check(lib.load().pea_rows_pack(lib.ptr(table), table.stride(0), int(col), int(width),
+                                                   lib.ptr(layout.own_nodes_i32), layout.own_count,
+                                                   lib.ptr(buf[self.rank * m:]), buf.stride(0), lib.current_stream()))
+            else:
+                buf[self.rank * m:self.rank * m + layout.own_count] = table[layout.own_nodes, col:col + width]
+        self._all_gather_blocks(buf, m, group)
+        if layout.other_nodes.numel():
+            if hip:
+                lib.check(lib.load().pea_rows_unpack(lib.ptr(buf), buf.stride(0), lib.ptr(layout.other_slots_i32), int(width),
+                                                     lib.ptr(layout.other_nodes_i32), layout.other_nodes_i32.numel(),
+                                                     lib.ptr(table), table.stride(0), int(col), lib.current_stream()))
+            else:
+                table[layout.other_nodes, col:col + width] = buf[layout.other_slots]
+
+    def fill_in_ids(self, table, col, width, ids, group=None):
+        """The same for an explicit list of node ids (duplicates allowed; e.g. the rows of a BPR batch): every rank
+        contributes the listed rows it owns, one all-reduce of [len(ids), width] (x + 0: exact), and every listed row of
+        `table` is overwritten with the owner's values."""
+        if self.world == 1 or ids.numel() == 0:
+            return
+        rows = self.gather_rows(table[:, col:col + width], ids, group)
+        if table.is_cuda and table.dtype == torch.float32 and width % 4 == 0 and col % 4 == 0 and table.stride(1) == 1:
+            lib = _hip()
+            ids32 = ids.to(torch.int32)
+            lib.check(lib.load().pea_rows_unpack(lib.ptr(rows), rows.stride(0), None, int(width), lib.ptr(ids32), ids32.numel(),
+                                                 lib.ptr(table), table.stride(0), int(col), lib.current_stream()))
+        else:
+            table[ids, col:col + width] = rows
+
+    def all_reduce_sum_(self, tensors, group=None):
+        """Sum every tensor of the list over the ranks, in place, with ONE collective on a flat copy (the ranks' shares of
+        the parameter gradients of a sharded training step)."""
+        tensors = [t for t in tensors if t is not None and t.numel()]
+        if self.world == 1 or not tensors or self.dry:
+            return
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        done = CommTimer.span(flat.device)
+        if dist.get_backend(group) == 'nccl':
+            dist.all_reduce(flat, group=group)
+        else:
+            host = flat.detach().cpu()
+            dist.all_reduce(host, group=group)
+            flat = host.to(flat.device)
+        if done is not None:
+            done.record()
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
 
     def _err_flag(self, device):
         from . import engine

@@ -180,6 +180,12 @@ size_t pea_grad_weight_workspace_bytes(void);
 int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes,
                     void *stream);
 int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *jobs_host, void *stream);
+/* Sharded training (one rank's share; the host mirror sums the shares with an all-reduce):
+ *   pea_grad_weight_sharded  the same reduction over the rows rank `shard_rank` owns (row i -> rank (i / tile) % world)
+ *   pea_dense_batch_rows     out = a w on the listed rows only (device int32 [n_rows]; e.g. the rows a rank owns) */
+int pea_grad_weight_sharded(int64_t n_rows, int shard_tile, int shard_world, int shard_rank, int n_jobs,
+                            const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream);
+int pea_dense_batch_rows(int64_t n_rows, const int32_t *rows, int n_jobs, const pea_dense_job *jobs_host, void *stream);
 
 /* ---- device-side BPR negative sampler (an addition next to the bit-exact host mirror of the reference's
  * datasets/movielens.py:920-940 in graph_recsys_benchmark_amd/utils/sampling.py) -----------------------------------
@@ -220,6 +226,12 @@ int pea_model_num_stages(const pea_model *model);
 int pea_model_forward_stage(pea_model *model, int stage, const float *const *params_host, const float *x,
                             const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
                             float *out_repr, float *out_stack, void *stream);
+/* the same stage of the TRAINING forward (model created with enable_backward): keeps what pea_model_backward_level
+ * reads.  Backward of a sharded model, per level: phase 0, host fills in the rows of dX / dO_s / side_s that other ranks
+ * own (sources of the reversed relation), phase 2 (GAT / GCN); SAGE: phase 0, host dense half + fill-in of dM_s, phase 1. */
+int pea_model_forward_stage_train(pea_model *model, int stage, const float *const *params_host, const float *x,
+                                  const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
+                                  float *out_repr, float *out_stack, void *stream);
 int pea_model_num_exchanges(const pea_model *model, int level);
 int pea_model_exchange_desc(const pea_model *model, int level, int k, pea_exchange_desc *out);
 

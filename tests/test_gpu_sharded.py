@@ -88,6 +88,63 @@ def test_sharded_narrow_layers_are_bit_exact(kind, hidden, repr_dim):
     mp.spawn(_worker, args=(2, _free_port(), kind, 1, hidden, repr_dim), nprocs=2, join=True)
 
 
+def _train_worker(rank, world, port, kind, heads):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from helpers import build_model, random_hin, random_state_dict
+        torch.cuda.set_device(0)
+        n, blocks, rel = random_hin(23, n_user=2500, n_item=700, n_attr=40, e_u2i=30000, e_attr=2000)
+        u2i, a2i = rel['u2i'], rel['a2i']
+        flip = lambda e: np.ascontiguousarray(e[::-1])
+        edges = [[u2i, flip(u2i)], [flip(u2i), u2i], [a2i, flip(u2i)], [flip(a2i), a2i, flip(u2i)]]
+        steps = [2, 2, 2, 3]
+        model = build_model(kind, n, edges, steps, 32, 32, 16, heads=heads)
+        model.load_state_dict(random_state_dict(model, 10, scale=0.25))
+        rng = np.random.default_rng(6)
+        (u0, u1), (i0, i1) = blocks['u'], blocks['i']
+        batch = torch.from_numpy(np.stack([rng.integers(u0, u1, 384), rng.integers(i0, i1, 384),
+                                           rng.integers(i0, i1, 384)], axis=1).astype(np.int64)).cuda()
+        model.train()
+        model.zero_grad()
+        ref_loss = model.loss(batch)                     # single-rank training step: the oracle of the sharded one
+        ref_loss.backward()
+        ref = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        model.shard(rank, world, tile=64)
+        model.zero_grad()
+        loss = model.loss(batch)
+        assert model._repr_partial
+        loss.backward()
+        # same forward rows, same replicated loss arithmetic: the loss value is bit-identical
+        assert torch.equal(loss.detach(), ref_loss.detach()), 'rank %d: loss %r vs %r' % (rank, loss, ref_loss)
+        for k, p in model.named_parameters():
+            assert p.grad is not None, k
+            w = ref[k]
+            scale = max(float(w.abs().max()), 1e-12)
+            err = float((p.grad - w).abs().max())
+            # the ranks' shares are summed in another order than the single-rank reduction: fp32 bound, not bit equality
+            assert err <= 2e-5 * scale + 1e-9, 'rank %d %s: max err %.3e vs scale %.3e' % (rank, k, err, scale)
+        # every rank holds the SAME gradients bit for bit (all-reduced / all-gathered), so the replicas stay in lockstep
+        sums = [None] * world
+        dist.all_gather_object(sums, [float(p.grad.double().sum()) for p in model.parameters()])
+        assert all(v == sums[0] for v in sums)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+        opt.step()
+        with torch.no_grad():
+            assert np.isfinite(float(model.loss(batch)))
+        model.eval()                                     # full table after the step: exchanges + all-gather
+        assert not model._repr_partial and bool(torch.isfinite(model.cached_repr).all())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind,heads,world', [('gat', 1, 2), ('gat', 2, 3), ('gcn', 1, 2), ('sage', 1, 2)])
+def test_sharded_training_step_matches_single_rank(kind, heads, world):
+    """model.shard() + loss.backward() (reference step solvers.py:213-216): loss bit-identical, every parameter gradient
+    within the fp32 bound of the single-rank gradients, identical on all ranks."""
+    mp.spawn(_train_worker, args=(world, _free_port(), kind, heads), nprocs=world, join=True)
+
+
 def _rccl_worker(rank, world, port):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -100,7 +157,7 @@ def _rccl_worker(rank, world, port):
         shard.world = 1
         # drive the RCCL branch directly (world 1: the only multi-rank-free way to touch it on a 1-GPU box)
         mine = buf[0:64]
-        dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1).clone())
+        dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1))    # IN PLACE (send block = own slice), as sharding.py does
         t = torch.ones(4, device='cuda')
         dist.all_reduce(t)
         torch.cuda.synchronize()
