@@ -193,9 +193,9 @@ class ShardLayout:
         buf = layout.buffer(width, table)
         hip = table.is_cuda and table.dtype == torch.float32 and width % 4 == 0 and col % 4 == 0 and table.stride(1) == 1 \
             and table.stride(0) % 4 == 0
+        lib = _hip() if hip else None
         if layout.own_count:
             if hip:
-                lib = _hip()
                 lib.check(lib.load().pea_rows_pack(lib.ptr(table), table.stride(0), int(col), int(width),
                                                    lib.ptr(layout.own_nodes_i32), layout.own_count,
                                                    lib.ptr(buf[self.rank * m:]), buf.stride(0), lib.current_stream()))
