@@ -117,13 +117,16 @@ def _train_worker(rank, world, port, kind, heads):
         loss.backward()
         # same forward rows, same replicated loss arithmetic: the loss value is bit-identical
         assert torch.equal(loss.detach(), ref_loss.detach()), 'rank %d: loss %r vs %r' % (rank, loss, ref_loss)
+        gscale = max(float(w.abs().max()) for w in ref.values())
         for k, p in model.named_parameters():
             assert p.grad is not None, k
             w = ref[k]
             scale = max(float(w.abs().max()), 1e-12)
             err = float((p.grad - w).abs().max())
             # the ranks' shares are summed in another order than the single-rank reduction: fp32 bound, not bit equality
-            assert err <= 2e-5 * scale + 1e-9, 'rank %d %s: max err %.3e vs scale %.3e' % (rank, k, err, scale)
+            # (a gradient that is zero up to rounding -- d att_i of a layer whose logits sit on one leaky-relu branch --
+            # is compared against the size of the model's gradients, not against itself)
+            assert err <= 2e-5 * scale + 1e-7 * gscale, 'rank %d %s: max err %.3e vs scale %.3e' % (rank, k, err, scale)
         # every rank holds the SAME gradients bit for bit (all-reduced / all-gathered), so the replicas stay in lockstep
         sums = [None] * world
         dist.all_gather_object(sums, [float(p.grad.double().sum()) for p in model.parameters()])
