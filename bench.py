@@ -401,7 +401,7 @@ def main():
         out['kernels_ms_per_step'] = {k: round(v[1] / args.steps, 4) for k, v in
                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}
     single = world == 1 and args.emulate_world <= 1
-    if single and args.train_steps > 0:
+    if args.train_steps > 0:          # sharded too: every rank steps its replica with the all-reduced gradients
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
 
         def train_step():
@@ -416,7 +416,9 @@ def main():
         tt, l = timed_region(train_step, args.train_steps)
         tt /= args.train_steps
         out['training_step'] = {'ms_per_step': tt * 1e3, 'steps': args.train_steps, 'loss': float(l),
-                                'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step'}
+                                'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step'
+                                        + (' (row-sharded over %d ranks: gradient-row fill-ins, gradient all-reduce, dx '
+                                           'all-gather)' % world if world > 1 else '')}
         if profile:
             lib.pea_profile_enable(1)
             train_step()
