@@ -199,10 +199,13 @@ struct AggGroup {
 // q instead of all N rows when the plan is sharded.
 struct RowMap {
     int tile = 1, world = 1, rank = 0;
+    int shift = -1;  // log2(tile) when the tile is a power of two (the default 256 is): shifts instead of 64-bit divisions
     int64_t n = 0;   // number of q values
     int64_t N = 0;   // rows of the tables
     __host__ __device__ int64_t row(int64_t q) const {
-        return world == 1 ? q : ((q / tile) * world + rank) * tile + q % tile;
+        if (world == 1) return q;
+        if (shift >= 0) return ((((q >> shift) * world) + rank) << shift) + (q & (int64_t)(tile - 1));
+        return ((q / tile) * world + rank) * tile + q % tile;
     }
 };
 inline RowMap make_rowmap(int64_t N, int tile, int world, int rank) {
@@ -215,6 +218,10 @@ inline RowMap make_rowmap(int64_t N, int tile, int world, int rank) {
     m.tile = tile;
     m.world = world;
     m.rank = rank;
+    if ((tile & (tile - 1)) == 0) {
+        m.shift = 0;
+        while ((1 << m.shift) < tile) ++m.shift;
+    }
     const int64_t tiles = (N + tile - 1) / tile;                       // all tiles
     const int64_t own_tiles = tiles > rank ? (tiles - rank + world - 1) / world : 0;
     m.n = own_tiles * tile;
