@@ -380,6 +380,9 @@ int launch_bwd_mode(const AggLaunch &base, hipStream_t stream) {
 // out[c] = sum_n A[n, c] * (S ? S[n, c / F] : 1) for c < W, rows in a fixed order (two stages, no atomics).
 // Stage 1: block b owns a contiguous row chunk; its 256 threads are 4 row lanes x 64 columns (256-byte coalesced
 // row pieces), partial sums of the 4 row lanes are folded through LDS in lane order.
+// MAPPED = false: rows 0..N-1 in place (one GPU); true: the rows a rank owns (RowMap), a separate instantiation so the
+// single-GPU loop keeps its plain addressing (the mapped form cost it 3x when it was the only one)
+template <bool MAPPED>
 __global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int F, const float *__restrict__ A, int lda,
                                                      const float *__restrict__ S, int lds, float *__restrict__ part) {
     __shared__ float red[4][64];
@@ -397,13 +400,18 @@ __global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int 
             for (; r + 28 < r1; r += 32) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = M.row(r + 4 * u);   // sharded plans: the q-th own row (rows past N: a short last tile)
-                    if (rr < M.N) acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
+                    if (MAPPED) {
+                        const int64_t rr = M.row(r + 4 * u);   // the q-th own row (rows past N: a short last tile)
+                        if (rr < M.N) acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
+                    } else {
+                        const int64_t rr = r + 4 * u;
+                        acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
+                    }
                 }
             }
             for (; r < r1; r += 4) {
-                const int64_t rr = M.row(r);
-                if (rr < M.N) acc[0] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
+                const int64_t rr = MAPPED ? M.row(r) : r;
+                if (!MAPPED || rr < M.N) acc[0] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
             }
             s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         }
@@ -464,7 +472,10 @@ int launch_colsum(const RowMap &rows, int W, int F, const float *A, int lda, con
                   float *out, hipStream_t stream) {
     if (W <= 0) return PEA_OK;
     ProfScope ps("colsum", stream, 0.0);
-    hipLaunchKernelGGL(colsum_stage1, dim3(kColsumParts), dim3(256), 0, stream, rows, W, F, A, lda, S, lds, part);
+    if (rows.world > 1)
+        hipLaunchKernelGGL(colsum_stage1<true>, dim3(kColsumParts), dim3(256), 0, stream, rows, W, F, A, lda, S, lds, part);
+    else
+        hipLaunchKernelGGL(colsum_stage1<false>, dim3(kColsumParts), dim3(256), 0, stream, rows, W, F, A, lda, S, lds, part);
     hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W, part, scale, out);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
