@@ -387,8 +387,12 @@ __global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int 
                                                      const float *__restrict__ S, int lds, float *__restrict__ part) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int64_t rows_per = (M.n + gridDim.x - 1) / gridDim.x;
+    // mapped: chunks are whole groups of 32 consecutive own rows, which share a tile whenever the tile is a multiple of
+    // 32 (the default 256 is), so one RowMap evaluation serves the 8 loads of a group
+    int64_t rows_per = (M.n + gridDim.x - 1) / gridDim.x;
+    if (MAPPED) rows_per = (rows_per + 31) / 32 * 32;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(M.n, r0 + rows_per);
+    const bool grouped = MAPPED && M.tile % 32 == 0;
     for (int c0 = 0; c0 < W; c0 += 64) {
         const int c = c0 + cl;
         float s = 0.f;
@@ -398,10 +402,11 @@ __global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int 
             const int k = c / F;
             int64_t r = r0 + rl;
             for (; r + 28 < r1; r += 32) {
+                const int64_t base = grouped ? M.row(r) : 0;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (MAPPED) {
-                        const int64_t rr = M.row(r + 4 * u);   // the q-th own row (rows past N: a short last tile)
+                        const int64_t rr = grouped ? base + 4 * u : M.row(r + 4 * u);   // rows past N: a short last tile
                         if (rr < M.N) acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
                     } else {
                         const int64_t rr = r + 4 * u;
