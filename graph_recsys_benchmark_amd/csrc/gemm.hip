@@ -362,6 +362,10 @@ __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(cons
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SkinnyArgs {
+    // > 0: every job has this many 64-row tiles and item i is (tile i / n_jobs, job i % n_jobs): the jobs of a level read
+    // adjacent column blocks of the SAME rows (one 256-byte piece each out of a 2304-byte row), so waves that run together
+    // then sweep whole rows instead of nine strided passes over the table (PEA_SKINNY_JOBMAJOR=1: the old job-major order)
+    int tiles_per_job;
     int n_items;
     int item_start[kMaxBatch + 1];  // first item (64-row tile) of job j
     int lds_off[kMaxBatch];         // float offset of job j's image: [KQ*16][16] weights + [16] bias
@@ -386,12 +390,18 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmBatch Bt, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stride = gridDim.x * 8;
     for (int item = blockIdx.x * 8 + wave; item < Sa.n_items; item += stride) {
-        int j = 0;
-        while (j + 1 < Bt.n && item >= Sa.item_start[j + 1]) ++j;
+        int j = 0, tile;
+        if (Sa.tiles_per_job > 0) {
+            tile = item / Bt.n;
+            j = item - tile * Bt.n;
+        } else {
+            while (j + 1 < Bt.n && item >= Sa.item_start[j + 1]) ++j;
+            tile = item - Sa.item_start[j];
+        }
         const GemmJob &J = Bt.j[j];
         const int *jrows = LISTED ? (J.rows ? J.rows : rows) : nullptr;
         const int64_t jn = (LISTED && J.rows) ? J.n_rows : n_rows;
-        const int64_t row0 = (int64_t)(item - Sa.item_start[j]) * (16 * G);
+        const int64_t row0 = (int64_t)tile * (16 * G);
         const int K = J.K1 + J.K2, K1 = J.K1, n_out = J.n_out, n_seg = J.n_seg;
         GemmSegment S[kMaxSegments];
 #pragma unroll
@@ -532,6 +542,13 @@ static int launch_skinny(const GemmBatch &Bt, const int *rows, int64_t n_rows, d
     }
     Sa.item_start[Bt.n] = items;
     Sa.n_items = items;
+    Sa.tiles_per_job = 0;
+    {
+        bool same = Bt.n > 1;
+        for (int j = 1; j < Bt.n; ++j) same = same && (Sa.item_start[j + 1] - Sa.item_start[j]) == Sa.item_start[1];
+        const char *env = getenv("PEA_SKINNY_JOBMAJOR");
+        if (same && !(env && atoi(env) != 0)) Sa.tiles_per_job = Sa.item_start[1];
+    }
     static int n_cu = 0;
     if (!n_cu) {
         hipDeviceProp_t prop;

@@ -46,6 +46,15 @@ def test_model_matches_reference_golden(name):
         else:
             b9 = torch.from_numpy(g.batch9).cuda()
             np.testing.assert_allclose(float(model.loss(b9)), g.out['loss_train'], rtol=RTOL)
+    if g.batch9 is not None:
+        # the same entity-aware loss under autograd (training step of --entity_aware=true): same value, and x receives
+        # the regulariser's gradient on top of the conv stack's
+        model.zero_grad()
+        b9 = torch.from_numpy(g.batch9).cuda()
+        loss = model.loss(b9)
+        np.testing.assert_allclose(float(loss), g.out['loss_train'], rtol=RTOL)
+        loss.backward()
+        assert model.x.grad is not None and bool(torch.isfinite(model.x.grad).all()) and float(model.x.grad.abs().max()) > 0
 
 
 @pytest.mark.parametrize('name', ['pea_gat_p3deep_h2_att', 'pea_gcn_p5s2_att', 'pea_sage_p5s2_att'])
