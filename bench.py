@@ -439,6 +439,8 @@ def main():
         del model
         torch.cuda.empty_cache()
         out['metapaths_13'] = thirteen_metapaths(dataset, args, device, batch, timed_region, not args.no_cpu_baseline)
+    if single and not args.no_extras and args.preset == 'ml25m_shaped' and not args.metapaths and args.scale == 1.0:
+        out['hbm_resident'] = hbm_resident_leg(args, device, timed_region, not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -480,6 +482,71 @@ def eval_variant(dataset, model, args, timed_region):
             'what': 'eval() forward over the full graph + pea_rank_eval of every user (rank, AUC, eval loss on device)',
             'parity_vs_cpu_oracle': {'users_checked': int(pick.size), 'score_max_abs_err': float(np.abs(got - want).max()),
                                      'ranks_differing': int((want_rank != got_rank).sum())}}
+
+
+def hbm_resident_leg(args, device, timed_region, with_check, scale=0.3):
+    """The same step on a workload whose gather tables do NOT fit the 256 MiB Infinity Cache (BASELINE config 5 at 30 %:
+    3 M nodes, 60 M edges, 16 metapaths, emb / hidden 128; item table of the 9-channel layer-2 gather: 600 k x 576 B):
+    the default workload's tables (26-42 MB) are cache resident, this one shows the kernels against HBM.  Its PMC
+    profile is profiles/r02/summary_r02s.json (traffic.json key 'stress_10m@0.3/gat').  Parity: sampled destination rows
+    of two channels recomputed in float64 on their 2-hop in-neighbourhood (oracle/rows64.py)."""
+    from graph_recsys_benchmark_amd import _lib
+    from graph_recsys_benchmark_amd.utils import SyntheticHIN, metapath_table
+    ds = SyntheticHIN('stress_10m', seed=2019, scale=scale)
+    model = build_model(ds, args.kind, device)
+    model.train()
+    batch = torch.from_numpy(ds.bpr_batch()).to(device)
+
+    def step():
+        with torch.no_grad():
+            return model.loss(batch)
+
+    for _ in range(3):
+        step()
+    steps = 8
+    dt, loss = timed_region(step, steps)
+    timed_region(step, steps, True)
+    prof = read_profile()
+    dt /= steps
+    eng = model._engine
+    sp, n = ds.spec, ds.num_nodes
+    flops = {}
+    if args.kind in ('gat', 'gcn'):
+        flops = {'gemm_mfma_shared': 2.0 * n * sp['emb_dim'] * sp['hidden_size'] * sp['num_metapaths'] * steps,
+                 'gemm_mfma_narrow': 2.0 * n * sp['hidden_size'] * sp['repr_dim'] * sp['num_metapaths'] * steps}
+    tab = load_traffic('stress_10m', args.kind, scale, 1)
+    dom = max(prof.items(), key=lambda kv: kv[1][1])
+    gathers = {k: v for k, v in prof.items() if v[3] > 0}
+    g = max(gathers.items(), key=lambda kv: kv[1][1])
+    out = {'workload': 'stress_10m x %g PEA%s forward+BPR: N=%d nodes, %d metapaths x 2 steps, %d messages/step, emb %d / hidden %d'
+                       % (scale, args.kind.upper(), n, sp['num_metapaths'], eng.messages, sp['emb_dim'], sp['hidden_size']),
+           'ms_per_step': dt * 1e3, 'edges_per_s': eng.messages / dt, 'loss': float(loss),
+           'hbm_floor_frac': eng.compulsory_bytes / (HBM_PEAK_GBS * 1e9) / dt,
+           'roofline': kernel_roofline(dom[0], dom[1], tab, flops),
+           'roofline_gather': kernel_roofline(g[0], g[1], tab, flops),
+           'kernels_ms_per_step': {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]}}
+    if with_check and args.kind in ('gat', 'sage'):
+        from oracle.rows64 import f64_rows_two_step
+        table = metapath_table(ds.dataset_args())
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            _, stack = model.forward(return_stack=True)
+        rng = np.random.default_rng(5)
+        u0, i0 = ds.type_accs['uid'], ds.type_accs['iid']
+        rows = np.unique(np.concatenate([rng.integers(u0, u0 + ds.num_uids, 12), rng.integers(ds.type_accs['attr_0'], n, 8)]))
+        err = scale_v = 0.0
+        for p in (0, 2):            # [u2i, u2i^T] and [attr_0 -> item, u2i^T]: destination rows = users / attribute nodes
+            rels = [np.ascontiguousarray(ds.edge_index_nps[r].astype(np.int64)[::-1]) if f else ds.edge_index_nps[r].astype(np.int64)
+                    for r, f in table[p]]
+            truth = f64_rows_two_step(args.kind, sd, p, rels[0], rels[1], rows)
+            got = stack[torch.from_numpy(rows).to(device), p].cpu().numpy()
+            err = max(err, float(np.abs(got - truth).max()))
+            scale_v = max(scale_v, float(np.abs(truth).max()))
+        out['parity_vs_float64_sampled_rows'] = {'rows': int(rows.size), 'channels': [1, 3], 'max_abs_err': err, 'max_abs_value': scale_v}
+    del model
+    torch.cuda.empty_cache()
+    _lib.load().pea_profile_enable(0)
+    return out
 
 
 def thirteen_metapaths(dataset, args, device, batch, timed_region, with_oracle):
