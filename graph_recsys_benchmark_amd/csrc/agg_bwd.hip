@@ -13,6 +13,8 @@
 // recomputed from the rows exactly as in agg.hip (packed att vectors carry log2(e); natural-unit gradients get ln 2).
 // Same work decomposition as the forward: short rows per lane subgroup, long rows / hub chunks per wave, hub chunks
 // folded in chunk order by a merge kernel -> bitwise reproducible gradients.
+#include <algorithm>
+
 #include "agg_common.h"
 
 namespace pea {
@@ -377,52 +379,85 @@ int launch_bwd_mode(const AggLaunch &base, hipStream_t stream) {
     return PEA_OK;
 }
 
-// out[c] = sum_n A[n, c] * (S ? S[n, c / F] : 1) for c < W, rows in a fixed order (two stages, no atomics).
-// Stage 1: block b owns a contiguous row chunk; its 256 threads are 4 row lanes x 64 columns (256-byte coalesced
-// row pieces), partial sums of the 4 row lanes are folded through LDS in lane order.
-// MAPPED = false: rows 0..N-1 in place (one GPU); true: the rows a rank owns (RowMap), a separate instantiation so the
-// single-GPU loop keeps its plain addressing (the mapped form cost it 3x when it was the only one)
-template <bool MAPPED>
-__global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int F, const float *__restrict__ A, int lda,
-                                                     const float *__restrict__ S, int lds, float *__restrict__ part) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    // mapped: chunks are whole groups of 32 consecutive own rows, which share a tile whenever the tile is a multiple of
-    // 32 (the default 256 is), so one RowMap evaluation serves the 8 loads of a group
-    int64_t rows_per = (M.n + gridDim.x - 1) / gridDim.x;
-    if (MAPPED) rows_per = (rows_per + 31) / 32 * 32;
+// out_k[c] = sum_n A[n, c] * (S_k ? S_k[n, c / F] : 1) for c < W (k = 0 and, optionally, 1: two scaled sums over ONE read
+// of A: the att_j and att_i gradients of a GAT level both weight T_s), rows in a fixed order (two stages, no atomics).
+// Stage 1: block b owns a contiguous row chunk; each of its 4 waves streams WHOLE rows -- lane l reads the float4
+// chunks l, l + 64, l + 128, l + 192 of a row, 4 rows in flight -- and the 4 waves' sums are folded through LDS in wave
+// order.  (Round 1 read 64-column pieces, one dword per lane: nine strided passes over a 2304-byte-row table at
+// 2.7 TB/s.)  MAPPED = false: rows 0..N-1 in place (one GPU); true: the rows a rank owns (RowMap).
+constexpr int kColsumT = 4;   // float4 chunks per lane: column blocks of up to 1024 columns
+// T = chunks per lane (W > 256: every lane of a wave works on ONE row); T == 1 and W <= 256: a row needs only
+// C = pow2ceil(W / 4) lanes, so a wave streams 64 / C rows side by side (the sub-rows are folded through LDS with the waves)
+template <bool MAPPED, bool TWO, int T>
+__global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int F, int C, const float *__restrict__ A, int lda,
+                                                     const float *__restrict__ S0, const float *__restrict__ S1, int lds,
+                                                     float *__restrict__ part, size_t part_stride) {
+    extern __shared__ float red[];  // [4 waves][NK][64 lanes * T] float4 slots
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = 64 / C;                    // rows per wave step (1 when T > 1)
+    const int rsub = lane / C, cl = lane % C;
+    const int64_t rows_per = (M.n + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(M.n, r0 + rows_per);
-    const bool grouped = MAPPED && M.tile % 32 == 0;
-    for (int c0 = 0; c0 < W; c0 += 64) {
-        const int c = c0 + cl;
-        float s = 0.f;
-        if (c < W) {
-            // 8 independent loads in flight per lane (fixed summation tree: 8 strided partial sums, then in order)
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const int k = c / F;
-            int64_t r = r0 + rl;
-            for (; r + 28 < r1; r += 32) {
-                const int64_t base = grouped ? M.row(r) : 0;
+    constexpr int NK = TWO ? 2 : 1;
+    for (int cb = 0; cb < W; cb += 256 * T) {
+        const int wb = min(W - cb, 256 * T);
+        float4 acc[NK][T];
+        bool on[T];
+        int hk[T];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (MAPPED) {
-                        const int64_t rr = grouped ? base + 4 * u : M.row(r + 4 * u);   // rows past N: a short last tile
-                        if (rr < M.N) acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
-                    } else {
-                        const int64_t rr = r + 4 * u;
-                        acc[u] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
-                    }
+        for (int t = 0; t < T; ++t) {
+            const int c = cb + 4 * (cl + 64 * t);
+            on[t] = c < cb + wb;
+            hk[t] = on[t] ? c / F : 0;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[k][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        constexpr int U = 4;
+        for (int64_t q = r0 + (int64_t)wave * R + rsub; q < r1; q += (int64_t)4 * R * U) {
+            float4 v[U][T];
+            float s0[U][T], s1[U][T];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t qq = q + (int64_t)4 * R * u;
+                int64_t rr = MAPPED ? M.row(qq < r1 ? qq : r0) : qq;
+                const bool rv = qq < r1 && (!MAPPED || rr < M.N);
+                if (!rv) rr = 0;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const bool ok = rv && on[t];
+                    v[u][t] = ok ? ld4(A + rr * lda + cb + 4 * (cl + 64 * t)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    s0[u][t] = (ok && S0) ? S0[rr * lds + hk[t]] : 1.f;
+                    if (TWO) s1[u][t] = ok ? S1[rr * lds + hk[t]] : 0.f;
                 }
             }
-            for (; r < r1; r += 4) {
-                const int64_t rr = MAPPED ? M.row(r) : r;
-                if (!MAPPED || rr < M.N) acc[0] += A[rr * lda + c] * (S ? S[rr * lds + k] : 1.f);
-            }
-            s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+            for (int u = 0; u < U; ++u)     // row order inside a lane: fixed
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    acc[0][t] = fma4(s0[u][t], v[u][t], acc[0][t]);
+                    if (TWO) acc[1][t] = fma4(s1[u][t], v[u][t], acc[1][t]);
+                }
         }
-        red[rl][cl] = s;
+        // every (wave, sub-row) stream parks its sums; lanes of wave 0 / sub-row 0 fold them in (wave, sub-row) order
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                st4(red + (((size_t)wave * NK + k) * T + t) * 256 + 4 * lane, acc[k][t]);
         __syncthreads();
-        if (rl == 0 && c < W) part[(size_t)blockIdx.x * W + c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+        if (wave == 0 && rsub == 0) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    if (!on[t]) continue;
+                    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int w = 0; w < 4; ++w)
+                        for (int rs = 0; rs < R; ++rs)
+                            r = add4(r, ld4(red + (((size_t)w * NK + k) * T + t) * 256 + 4 * (rs * C + cl)));
+                    st4(part + (size_t)k * part_stride + (size_t)blockIdx.x * W + cb + 4 * (cl + 64 * t), r);
+                }
+        }
         __syncthreads();
     }
 }
@@ -473,17 +508,50 @@ int launch_gat_backward(AggMode mode, const AggGroup *groups, int n_groups, hipS
     return mode == AGG_GAT_BWD_D ? launch_bwd_mode<AGG_GAT_BWD_D>(base, stream) : launch_bwd_mode<AGG_GAT_BWD_S>(base, stream);
 }
 
-int launch_colsum(const RowMap &rows, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
-                  float *out, hipStream_t stream) {
+template <bool MP, bool TW>
+static void colsum_dispatch(int T, size_t lds_bytes, hipStream_t stream, const RowMap &rows, int W, int F, int C, const float *A,
+                            int lda, const float *S0, const float *S1, int lds, float *part, size_t part_stride) {
+#define PEA_COLSUM(TT)                                                                                                        \
+    hipLaunchKernelGGL((colsum_stage1<MP, TW, TT>), dim3(kColsumParts), dim3(256), lds_bytes, stream, rows, W, F, C, A, lda, S0, \
+                       S1, lds, part, part_stride)
+    if (T == 1) PEA_COLSUM(1);
+    else if (T == 2) PEA_COLSUM(2);
+    else if (T == 3) PEA_COLSUM(3);
+    else PEA_COLSUM(4);
+#undef PEA_COLSUM
+}
+
+int launch_colsum2(const RowMap &rows, int W, int F, const float *A, int lda, const float *S0, const float *S1, int lds,
+                   float scale, float *part, float *out0, float *out1, hipStream_t stream) {
     if (W <= 0) return PEA_OK;
+    PEA_REQUIRE(W % 4 == 0 && lda % 4 == 0 && F % 4 == 0, PEA_ERR_ARG, "colsum: widths / strides must be multiples of 4");
     ProfScope ps("colsum", stream, 0.0);
-    if (rows.world > 1)
-        hipLaunchKernelGGL(colsum_stage1<true>, dim3(kColsumParts), dim3(256), 0, stream, rows, W, F, A, lda, S, lds, part);
-    else
-        hipLaunchKernelGGL(colsum_stage1<false>, dim3(kColsumParts), dim3(256), 0, stream, rows, W, F, A, lda, S, lds, part);
-    hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W, part, scale, out);
+    const bool two = S1 != nullptr;
+    const size_t part_stride = (size_t)kColsumParts * W;   // second output's partials follow the first's
+    const int w4 = W / 4;
+    const int T = std::min(kColsumT, (w4 + 63) / 64);
+    int C = 64;
+    if (T == 1) {
+        C = 1;
+        while (C < w4) C <<= 1;
+    }
+    const size_t lds_bytes = (size_t)4 * (two ? 2 : 1) * T * 256 * sizeof(float);
+    const bool mapped = rows.world > 1;
+    if (mapped && two) colsum_dispatch<true, true>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
+    else if (mapped) colsum_dispatch<true, false>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
+    else if (two) colsum_dispatch<false, true>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
+    else colsum_dispatch<false, false>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
+    hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W, part, scale, out0);
+    if (two)
+        hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W,
+                           part + part_stride, scale, out1);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
+}
+
+int launch_colsum(const RowMap &rows, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
+                  float *out, hipStream_t stream) {
+    return launch_colsum2(rows, W, F, A, lda, S, nullptr, lds, scale, part, out, nullptr, stream);
 }
 
 int launch_relu_mask(const RowMap &rows, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream) {

@@ -236,6 +236,9 @@ constexpr int kColsumParts = 512;
 int launch_gat_backward(AggMode mode, const AggGroup *groups, int n_groups, hipStream_t stream);
 int launch_colsum(const RowMap &rows, int W, int F, const float *A, int lda, const float *S, int lds, float scale, float *part,
                   float *out, hipStream_t stream);
+// two scaled column sums over ONE read of A (S1 == null: one); `part` holds 2 * kColsumParts * W floats
+int launch_colsum2(const RowMap &rows, int W, int F, const float *A, int lda, const float *S0, const float *S1, int lds,
+                   float scale, float *part, float *out0, float *out1, hipStream_t stream);
 int launch_relu_mask(const RowMap &rows, int W, float *G, int ldg, const float *O, int ldo, hipStream_t stream);
 
 // ---------------------------------------------------------------- dense transform (gemm.hip)

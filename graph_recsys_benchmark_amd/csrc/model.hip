@@ -318,7 +318,7 @@ int build_schedule(pea_model *m) {
         }
         m->off_dx = off;      off = pad_off(off + (size_t)N * (size_t)m->ld_x);
         m->off_gpack = off;   m->gpack_floats = m->pack_floats; off = pad_off(off + m->gpack_floats);
-        m->off_colsum = off;  off = pad_off(off + (size_t)kColsumParts * (size_t)std::max(max_w, m->ld_x));
+        m->off_colsum = off;  off = pad_off(off + (size_t)2 * kColsumParts * (size_t)std::max(max_w, m->ld_x));  // two sums per pass
     }
     m->total_floats = off;
     return PEA_OK;

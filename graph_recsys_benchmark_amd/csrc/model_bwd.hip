@@ -218,12 +218,18 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         const int ldg = g0.last ? m->ld_x : L.ld_o;
         if (part_a) PEA_TRY(launch_colsum(own, W, W, G, ldg, nullptr, 0, 1.0f, colsum_part, gpack + g0.bias_off, stream));
         if (d.kind == PEA_KIND_GAT) {
-            if (part_b)
-                PEA_TRY(launch_colsum(own, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_das + g0.a_k, L.ld_k, 1.0f, colsum_part,
-                                      gpack + L.att_src_off + g0.col, stream));
-            if (part_a)
-                PEA_TRY(launch_colsum(own, W, g0.F, T + g0.col, L.ld_t, wsf + L.off_dad + g0.a_k, L.ld_k, 1.0f, colsum_part,
-                                      gpack + L.att_dst_off + g0.col, stream));
+            float *das = wsf + L.off_das + g0.a_k, *dad = wsf + L.off_dad + g0.a_k;
+            if (part_a && part_b) {  // one GPU: both attention-vector gradients weight T_s: one pass over it
+                PEA_TRY(launch_colsum2(own, W, g0.F, T + g0.col, L.ld_t, das, dad, L.ld_k, 1.0f, colsum_part,
+                                       gpack + L.att_src_off + g0.col, gpack + L.att_dst_off + g0.col, stream));
+            } else {
+                if (part_b)
+                    PEA_TRY(launch_colsum(own, W, g0.F, T + g0.col, L.ld_t, das, L.ld_k, 1.0f, colsum_part,
+                                          gpack + L.att_src_off + g0.col, stream));
+                if (part_a)
+                    PEA_TRY(launch_colsum(own, W, g0.F, T + g0.col, L.ld_t, dad, L.ld_k, 1.0f, colsum_part,
+                                          gpack + L.att_dst_off + g0.col, stream));
+            }
         }
         gi = gj;
     }
