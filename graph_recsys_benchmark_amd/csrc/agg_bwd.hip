@@ -171,9 +171,21 @@ __global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
 #pragma unroll
             for (int u = 0; u < U; ++u) edge_s<F4T>(P, r, g[u], sd[u], ok[u], lane, pos, F4, pow2, acc, dzs);
         }
-        if (P.self_loop)
-            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on, lane,
-                        pos, F4, pow2, acc, dzs);
+        if (P.self_loop) {
+            const bool lone = P.deg0_self && P.deg0_self[row] != 0;   // wave-divergent per subgroup: both forms are lane-local
+            const float4 gs = ld4(row_at(P.feat + c4, row, P.ld_feat));
+            float4 sd = make_float4(0.f, 0.f, 1.f, 0.f);
+            if (!lone) sd = ld4(row_at(P.side + 4 * k, row, P.ld_side));
+            float4 acc2 = acc;
+            float dz2 = dzs;
+            edge_s<F4T>(P, r, gs, sd, row_on, lane, pos, F4, pow2, acc2, dz2);   // head sums are cross-lane: every lane runs it
+            if (lone) {
+                if (row_on) acc = add4(acc, gs);        // alpha = 1 exactly, d z = 0
+            } else {
+                acc = acc2;
+                dzs = dz2;
+            }
+        }
         if (active) finish_s(P, r, row, c4, acc, dzs);
     }
 }
@@ -268,6 +280,8 @@ __global__ __launch_bounds__(kBlock) void bwd_long_kernel(const AggLaunch L) {
     if (P.self_loop) {
         if (MODE == AGG_GAT_BWD_D) {
             dsum += dz_edge_d<F4T>(P, rd, rd.hself, lane, pos, F4, pow2);
+        } else if (P.deg0_self && P.deg0_self[row] != 0) {   // wave-uniform: one row per wave
+            if (row_on) acc = add4(acc, ld4(row_at(P.feat + c4, row, P.ld_feat)));
         } else {
             edge_s<F4T>(P, rs, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on, lane,
                         pos, F4, pow2, acc, dsum);
@@ -314,9 +328,14 @@ __global__ __launch_bounds__(kBlock) void bwd_merge_kernel(const AggLaunch L) {
         if (sub == 0 && active) finish_d(P, r, row, c4, dsum);
     } else {
         const RowS r = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
-        if (P.self_loop)
-            edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on, lane,
-                        pos, F4, pow2, acc, dsum);
+        if (P.self_loop) {
+            if (P.deg0_self && P.deg0_self[row] != 0) {   // wave-uniform (one hub row per wave): see bwd_short_kernel
+                if (row_on) acc = add4(acc, ld4(row_at(P.feat + c4, row, P.ld_feat)));
+            } else {
+                edge_s<F4T>(P, r, ld4(row_at(P.feat + c4, row, P.ld_feat)), ld4(row_at(P.side + 4 * k, row, P.ld_side)), row_on,
+                            lane, pos, F4, pow2, acc, dsum);
+            }
+        }
         if (sub == 0 && active) finish_s(P, r, row, c4, acc, dsum);
     }
 }

@@ -190,6 +190,10 @@ struct AggGroup {
     int hot_K;
     double hot_frac;
     const unsigned char *row_active;  // optional [N]: 0 = the row's output gradient is exactly zero (D: row, S: gathered row)
+    // S pass: [N] flags of the FORWARD relation: 1 = the row has no incoming edge there, its softmax is its self loop
+    // alone (alpha = 1, d z = 0 up to rounding): the D pass skips such rows, the S pass adds g_row for the self loop
+    // without a side record, and their d a_dst reads as 0 (the level's d a_dst buffer is cleared first)
+    const unsigned char *deg0_self;
     int ld_g, ld_side, ld_k;
 };
 

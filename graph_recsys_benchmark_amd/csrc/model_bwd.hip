@@ -131,6 +131,10 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
     PEA_REQUIRE(phase == 0 || sharded, PEA_ERR_ARG, "backward: phase 2 is the second half of a SHARDED level");
     const bool part_a = phase == 0;               // masks, D pass, reductions over what own rows already hold
     const bool part_b = phase == 2 || !sharded;   // gathers over the reversed relation, reductions of their results
+    if (d.kind == PEA_KIND_GAT && part_a) {
+        // rows whose softmax is their self loop alone are skipped by the D pass (alpha = 1, d z = 0): their d a_dst reads 0
+        PEA_HIP(hipMemsetAsync(wsf + L.off_dad, 0, (size_t)N * (size_t)L.ld_k * sizeof(float), stream));
+    }
     std::vector<AggGroup> gd, gsrc;
     for (const GroupPlan &g : L.groups) {
         const int rr = m->reverse_of[(size_t)g.rel];
@@ -189,6 +193,10 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             D.feat = wsf + g.xch_off;
             D.ld_feat = g.xch_ld;
         }
+        if (loops) {  // edge-less rows come first in the short-row list: not visited (no side record, d a_dst = 0)
+            D.short_rows = R.short_rows + R.n_short0;
+            D.n_short = R.n_short - R.n_short0;
+        }
         if (part_a) PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, &D, 1, stream));
         // S pass: source rows = destination rows of the reversed relation, gathers g_i and the side records
         AggGroup S = a;
@@ -202,6 +210,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         S.ksum = wsf + L.off_das + g.a_k;
         S.out = dT + g.col;
         S.ld_out = L.ld_t;
+        S.deg0_self = loops ? R.deg0 : nullptr;
         if (part_b) PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, &S, 1, stream));
     }
     // Gradient reductions, one launch per run of groups whose columns (and heads) are contiguous:
