@@ -173,3 +173,19 @@ def _rccl_worker(rank, world, port):
 def test_rccl_backend_single_rank_smoke():
     """backend 'nccl' is RCCL on ROCm: the collective calls the sharded forward issues work on this box."""
     mp.spawn(_rccl_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment: the script starts its own two ranks before
+    anything touches a GPU and rank 0 prints the one JSON line (here over gloo, both ranks on the box's one GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--preset', 'ml_small',
+                        '--steps', '3', '--warmup', '1', '--train-steps', '2'], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['parallelism'] == 'rows2'
+    assert out['exchange_ms_per_step'] is not None and np.isfinite(out['training_step']['loss'])
