@@ -88,6 +88,8 @@ class SourceLayout:
 
 
 class ShardLayout:
+    _inplace_ok = True   # see _all_gather_blocks
+
     def __init__(self, num_nodes, rank=0, world=1, tile=256):
         if not (0 <= rank < world) or tile <= 0:
             raise ValueError('bad shard (rank %d of %d, tile %d)' % (rank, world, tile))
@@ -123,8 +125,15 @@ class ShardLayout:
         done = CommTimer.span(buf.device)
         if dist.get_backend(group) == 'nccl':
             # RCCL all-gather IN PLACE: the send block is this rank's slice of the receive buffer (ncclAllGather's
-            # documented in-place form, sendbuff == recvbuff + rank * count)
-            dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=group)
+            # documented in-place form, sendbuff == recvbuff + rank * count).  Should a torch / RCCL build refuse aliased
+            # buffers, the send block is copied out once and for all later calls (slower by one copy, same result).
+            if ShardLayout._inplace_ok:
+                try:
+                    dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=group)
+                except RuntimeError:
+                    ShardLayout._inplace_ok = False
+            if not ShardLayout._inplace_ok:
+                dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1).clone(), group=group)
         else:                                                                          # gloo (CPU tests / rehearsal)
             parts = [torch.empty(mine.shape, dtype=buf.dtype) for _ in range(self.world)]
             dist.all_gather(parts, mine.detach().cpu().contiguous(), group=group)
