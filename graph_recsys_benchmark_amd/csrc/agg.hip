@@ -15,6 +15,7 @@
 //                 with xor shuffles
 //   hub rows    : chunks write (m, s, acc) records; a merge kernel folds them in chunk order
 #include <algorithm>
+#include <cstdlib>
 
 #include "agg_common.h"
 
@@ -308,6 +309,195 @@ __global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
     long_item<G, MODE, F4T, 4, false>(P, it, lane, nullptr, nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "fat lanes": the same item with V = 4 * V4 consecutive columns per lane instead of 4.
+// The thin kernel spends 12 (W = 112) / 8 (W = 64) vector instructions per edge, most of them per-edge bookkeeping that
+// every lane of a row repeats (addressing, logit pipeline, mask, exp), and sits at 86 % / 68 % VALU-busy on the
+// 25m-shaped graph (profiles/r02/sq_counters_agg_long_plain_r02.json).  With 16 columns per lane a row of W columns needs
+// W / 16 lanes, a wave works on 64 / G edges per instruction instead of 64 / (4 G), the head sum of the logit shrinks
+// (HL = F / V lanes per head; one lane per 16-wide channel: no cross-lane step at all), and every lane reads 64 contiguous
+// bytes of its row.  Same edge order and the same 4-edge softmax batches as the thin kernel; the per-lane dot products
+// group the columns differently, so logits differ in the last bits between the two (each row is always handled by the
+// same one of them: the choice depends on the group's W and F only).
+template <int G, int MODE, int HL, int V4>
+__device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem it, const int lane) {
+    constexpr int NSG = kWave / G, U = 4, V = 4 * V4;
+    const int sub = lane / G, sl = lane % G;
+    const bool active = sl * V < P.W;
+    const int c0 = active ? sl * V : 0;
+    const float *feat = P.feat + c0;
+    const float *feat_self = P.feat_self + c0;
+    const int row = it.row;
+    const int pos = sl % HL;
+    const int kk = 2 * (c0 / P.F);
+
+    float sm = kNegBig, ss = 0.f;   // running softmax state of this lane's head (GAT)
+    float4 acc[V4];                 // weighted sum (GAT) / plain sum (GCN, MEAN)
+#pragma unroll
+    for (int v = 0; v < V4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float a_d = 0.f, di = 0.f;
+    const float slope = P.neg_slope;
+    float4 att_s[V4], h_self[V4];
+    if (MODE == AGG_GAT) {
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < V4; ++v) {
+            att_s[v] = ld4(P.att_src + c0 + 4 * v);
+            h_self[v] = ld4(row_at(feat_self, row, P.ld_self) + 4 * v);
+            d += dot4(h_self[v], ld4(P.att_dst + c0 + 4 * v));
+        }
+        a_d = head_sum<HL>(d, lane, pos, HL, true);
+    } else if (MODE == AGG_GCN) {
+        di = P.dinv_self[row];
+    }
+    int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
+    for (int base = it.beg; base < it.end; base += kWave) {
+        const int nxt = base + kWave + lane;
+        const int src_next = nxt < it.end ? P.col[nxt] : -1;  // next batch of ids is in flight during this one
+        const int cnt = min(kWave, it.end - base);
+        for (int t = 0; t < cnt; t += NSG * U) {
+            int jj[U];
+            bool ok[U];
+            float4 h[U][V4];
+            float a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = t + u * NSG + sub;
+                const int j = __shfl(src, idx & (kWave - 1));
+                ok[u] = idx < cnt && j >= 0;
+                jj[u] = ok[u] ? j : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float *p = row_at(feat, jj[u], P.ld_feat);
+#pragma unroll
+                for (int v = 0; v < V4; ++v) h[u][v] = ld4(p + 4 * v);
+                if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
+            }
+            if (MODE == AGG_GAT) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int v = 0; v < V4; ++v) d += dot4(h[u][v], att_s[v]);
+                    a[u] = head_sum<HL>(d, lane, pos, HL, true);
+                }
+                // one softmax update per 4 edges, as in the thin kernel
+                float e[U];
+                float mn = sm;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float z = leaky(a[u] + a_d, slope);
+                    e[u] = ok[u] ? z : -INFINITY;
+                    mn = fmaxf(mn, e[u]);
+                }
+                const float fs = __builtin_amdgcn_exp2f(sm - mn);
+                sm = mn;
+                ss *= fs;
+#pragma unroll
+                for (int v = 0; v < V4; ++v) acc[v] = scale4(acc[v], fs);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float p = __builtin_amdgcn_exp2f(e[u] - mn);
+                    ss += p;
+#pragma unroll
+                    for (int v = 0; v < V4; ++v) acc[v] = fma4(p, h[u][v], acc[v]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (MODE == AGG_GCN) {
+                        const float w = ok[u] ? a[u] * di : 0.f;
+#pragma unroll
+                        for (int v = 0; v < V4; ++v) acc[v] = fma4(w, h[u][v], acc[v]);
+                    } else if (ok[u]) {
+#pragma unroll
+                        for (int v = 0; v < V4; ++v) acc[v] = add4(acc[v], h[u][v]);
+                    }
+                }
+            }
+        }
+        src = src_next;
+    }
+    // fold the NSG subgroup states (xor butterfly: every lane ends with the same value)
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) {
+        if (MODE == AGG_GAT) {
+            const float m2 = __shfl_xor(sm, off), s2 = __shfl_xor(ss, off);
+            const float mn = fmaxf(sm, m2);
+            const float f1 = __builtin_amdgcn_exp2f(sm - mn), f2 = __builtin_amdgcn_exp2f(m2 - mn);
+            ss = ss * f1 + s2 * f2;
+#pragma unroll
+            for (int v = 0; v < V4; ++v) acc[v] = add4(scale4(acc[v], f1), scale4(shfl_xor4(acc[v], off), f2));
+            sm = mn;
+        } else {
+#pragma unroll
+            for (int v = 0; v < V4; ++v) acc[v] = add4(acc[v], shfl_xor4(acc[v], off));
+        }
+    }
+    if (it.slot >= 0) {  // hub chunk: partial record in plain column order (the merge kernel is layout-agnostic)
+        if (sub == 0 && active) {
+            const int nk = P.W / P.F;
+            float *rec = P.partial + (size_t)it.slot * (size_t)(P.W + 2 * nk);
+#pragma unroll
+            for (int v = 0; v < V4; ++v) st4(rec + c0 + 4 * v, acc[v]);
+            if (MODE == AGG_GAT && c0 % P.F == 0) {
+                rec[P.W + kk] = sm;
+                rec[P.W + kk + 1] = ss;
+            }
+        }
+        return;
+    }
+    if (P.self_loop) {
+        if (MODE == AGG_GAT) {
+            float d = 0.f;
+#pragma unroll
+            for (int v = 0; v < V4; ++v) d += dot4(h_self[v], att_s[v]);
+            const float e = leaky(head_sum<HL>(d, lane, pos, HL, true) + a_d, slope);
+            // Soft::push: one exp, rescale either the state or the newcomer
+            const float dd = e - sm;
+            const float x = __builtin_amdgcn_exp2f(-fabsf(dd));
+            const bool up = dd > 0.f;
+            const float fs = up ? x : 1.f, p = up ? 1.f : x;
+            sm = up ? e : sm;
+            ss = fmaf(ss, fs, p);
+#pragma unroll
+            for (int v = 0; v < V4; ++v) {
+                acc[v].x = fmaf(acc[v].x, fs, p * h_self[v].x);
+                acc[v].y = fmaf(acc[v].y, fs, p * h_self[v].y);
+                acc[v].z = fmaf(acc[v].z, fs, p * h_self[v].z);
+                acc[v].w = fmaf(acc[v].w, fs, p * h_self[v].w);
+            }
+        } else if (MODE == AGG_GCN) {
+#pragma unroll
+            for (int v = 0; v < V4; ++v) acc[v] = fma4(di * di, ld4(row_at(feat_self, row, P.ld_self) + 4 * v), acc[v]);
+        }
+    }
+    if (sub == 0 && active) {
+        Soft st;
+        st.m = sm;
+        st.s = ss;
+#pragma unroll
+        for (int v = 0; v < V4; ++v) {   // finish_row per float4 chunk (stats are written by the head's first chunk)
+            st.acc = acc[v];
+            finish_row<MODE>(P, row, c0 + 4 * v, it.end - it.beg, st, acc[v]);
+        }
+    }
+}
+
+template <int G, int MODE, int HL, int V4>
+__global__ __launch_bounds__(kBlock) void agg_long_fat_kernel(const AggLaunch L) {
+    const int gi = find_group(L);
+    const AggGroup &P = L.g[gi];
+    const int wave = (int)threadIdx.x / kWave;
+    const int lane = (int)threadIdx.x % kWave;
+    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + wave;
+    if (item >= P.n_long) return;  // wave-uniform
+    const LongItem it = P.long_items[item];
+    if (it.slot == -2) return;  // padding of the XCD-affine item layout (plan.hip)
+    long_item_fat<G, MODE, HL, V4>(P, it, lane);
+}
+
 // One 1024-thread workgroup per CU, persistent: it fills the LDS image once, then its 16 waves walk the item list.  The
 // walk keeps the launch order's placement: the plain kernel hands items [4b, 4b + 4) to workgroup b, workgroups are dealt
 // round-robin over the 8 XCDs, and the plan lays sliced hub rows out so that workgroup b works on source slice b % 8.  Here
@@ -456,7 +646,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     double pull_plain = 0.0, alg_plain = 0.0;
     for (int i = 0; i < n_sel; ++i) {
         const AggGroup &g = base.g[sel[i]];
-        if (g.n_long <= 0 || g.hot_col) continue;
+        if (g.n_long <= 0 || g.hot_col || g.skip_long) continue;
         L.blk_start[L.n_groups] = blocks;
         L.g[L.n_groups++] = g;
         blocks += ((g.n_long + 3) / 4 + 7) / 8 * 8;  // groups start on a multiple of 8 workgroups (XCD round-robin)
@@ -473,7 +663,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     // groups with an LDS image of their hottest sources: one persistent launch each
     for (int i = 0; i < n_sel; ++i) {
         const AggGroup &g = base.g[sel[i]];
-        if (g.n_long <= 0 || !g.hot_col) continue;
+        if (g.n_long <= 0 || !g.hot_col || g.skip_long) continue;
         if (MODE == AGG_WSUM) return PEA_ERR_ARG;  // never planned (per-edge weights are indexed by CSR slot)
         L.n_groups = 1;
         L.blk_start[0] = 0;
@@ -528,8 +718,103 @@ int launch_g(const AggLaunch &base, int cls, const int *sel, int n, hipStream_t 
     return launch_for_g<G, MODE, 0>(base, sel, n, stream);
 }
 
+// ---- fat-lane long-row launches (16 columns per lane): groups of W >= 64, W % 16 == 0, whole heads per lane group
 template <int MODE>
-int launch_mode(const AggLaunch &base, hipStream_t stream) {
+const char *fat_name(int G) {
+    static char names[3][32];
+    const int i = G == 4 ? 0 : G == 8 ? 1 : 2;
+    if (!names[i][0]) {
+        const char *m = MODE == AGG_GAT ? "gat" : MODE == AGG_GCN ? "gcn" : "mean";
+        snprintf(names[i], sizeof(names[i]), "agg_long_fat_g%d_%s", G, m);
+    }
+    return names[i];
+}
+
+inline int fat_lanes(int W) {  // lanes per edge at 16 columns per lane (4, 8 or 16), 0 = not eligible
+    if (W < 64 || W % 16 != 0 || W > 256) return 0;
+    int g = 4;
+    while (g * 16 < W) g <<= 1;
+    return g;
+}
+
+template <int G, int MODE, int HL>
+int launch_fat(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
+    AggLaunch L;
+    L.n_groups = 0;
+    int blocks = 0;
+    double alg = 0.0, pull = 0.0, table = 0.0;
+    for (int i = 0; i < n_sel; ++i) {
+        const AggGroup &g = base.g[sel[i]];
+        L.blk_start[L.n_groups] = blocks;
+        L.g[L.n_groups++] = g;
+        blocks += ((g.n_long + 3) / 4 + 7) / 8 * 8;  // same item -> workgroup -> XCD placement as the thin kernel
+        const double per_msg = 4.0 * g.W + 4.0 * g.idx_share + (MODE == AGG_GAT ? 4.0 * (g.W / g.F) : MODE == AGG_GCN ? 4.0 * g.idx_share : 0.0);
+        alg += per_msg * g.msgs_long;
+        pull += (4.0 * g.W + 4.0 + (MODE == AGG_GCN ? 4.0 : 0.0)) * g.msgs_long;
+        table = std::max(table, g.table_rows * 4.0 * g.W);
+    }
+    L.blk_start[L.n_groups] = blocks;
+    if (blocks <= 0) return PEA_OK;
+    ProfScope ps(fat_name<MODE>(G), stream, alg, pull, table);
+    hipLaunchKernelGGL((agg_long_fat_kernel<G, MODE, HL, 4>), dim3(blocks), dim3(kBlock), 0, stream, L);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+template <int G, int MODE>
+int launch_fat_hl(const AggLaunch &base, int HL, const int *sel, int n, hipStream_t stream) {
+    if (MODE != AGG_GAT) return launch_fat<G, MODE, 1>(base, sel, n, stream);
+    switch (HL) {
+        case 1: return launch_fat<G, MODE, 1>(base, sel, n, stream);
+        case 2: return launch_fat<G, MODE, 2>(base, sel, n, stream);
+        case 4: return launch_fat<G, MODE, 4>(base, sel, n, stream);
+        case 8: return launch_fat<G, MODE, (G >= 8 ? 8 : 1)>(base, sel, n, stream);
+        default: return launch_fat<G, MODE, (G >= 16 ? 16 : 1)>(base, sel, n, stream);
+    }
+}
+
+// Launches the long items of every eligible group with the fat-lane kernel and marks those groups (skip_long).
+template <int MODE>
+int launch_fat_groups(AggLaunch &base, hipStream_t stream) {
+    if (MODE == AGG_WSUM) return PEA_OK;
+    const char *env = getenv("PEA_FAT");
+    if (env && atoi(env) == 0) return PEA_OK;
+    int lanes[kMaxAggGroups], hl[kMaxAggGroups];
+    for (int i = 0; i < base.n_groups; ++i) {
+        const AggGroup &g = base.g[i];
+        lanes[i] = hl[i] = 0;
+        if (g.n_long <= 0 || g.hot_col) continue;
+        const int G = fat_lanes(g.W);
+        if (!G) continue;
+        int h = 1;
+        if (MODE == AGG_GAT) {
+            if (g.F % 16 != 0) continue;
+            h = g.F / 16;
+            if ((h & (h - 1)) != 0 || h > G) continue;   // whole heads on power-of-two lane groups
+        }
+        lanes[i] = G;
+        hl[i] = h;
+    }
+    for (int G = 4; G <= 16; G <<= 1)
+        for (int h = 1; h <= G; h <<= 1) {
+            int sel[kMaxAggGroups], n = 0;
+            for (int i = 0; i < base.n_groups; ++i)
+                if (lanes[i] == G && hl[i] == h) sel[n++] = i;
+            if (!n) continue;
+            switch (G) {
+                case 4: PEA_TRY((launch_fat_hl<4, MODE>(base, h, sel, n, stream))); break;
+                case 8: PEA_TRY((launch_fat_hl<8, MODE>(base, h, sel, n, stream))); break;
+                default: PEA_TRY((launch_fat_hl<16, MODE>(base, h, sel, n, stream))); break;
+            }
+            for (int q = 0; q < n; ++q) base.g[sel[q]].skip_long = 1;
+        }
+    return PEA_OK;
+}
+
+template <int MODE>
+int launch_mode(const AggLaunch &base_in, hipStream_t stream) {
+    AggLaunch base = base_in;
+    PEA_TRY(launch_fat_groups<MODE>(base, stream));
     const int classes[3] = {0, 4, -1};  // -1 stands for "== G"
     for (int G = 4; G <= 64; G <<= 1) {
         for (int ci = 0; ci < 3; ++ci) {

@@ -194,6 +194,7 @@ struct AggGroup {
     // alone (alpha = 1, d z = 0 up to rounding): the D pass skips such rows, the S pass adds g_row for the self loop
     // without a side record, and their d a_dst reads as 0 (the level's d a_dst buffer is cleared first)
     const unsigned char *deg0_self;
+    int skip_long;         // host-side: the long items of this group were launched by the fat-lane kernel already
     int ld_g, ld_side, ld_k;
 };
 
