@@ -324,11 +324,15 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
     constexpr int NSG = kWave / G, U = 4, V = 4 * V4;
     const int sub = lane / G, sl = lane % G;
     const bool active = sl * V < P.W;
-    const int c0 = active ? sl * V : 0;
+    // the HL lanes of a head interleave its float4 chunks: lane (head h, position q) holds chunks q, q + HL, q + 2 HL, ...
+    // of the head, so ONE load instruction reads HL * 16 contiguous bytes per edge (64+ bytes for HL >= 4); with 16
+    // contiguous columns per lane every instruction touched every cache line of the row (measured 2x slower)
+    const int pos = sl % HL;
+    const int c0 = active ? (sl / HL) * P.F + 4 * pos : 0;   // column of chunk 0; chunk v sits at c0 + 4 * HL * v
+    constexpr int CS = 4 * HL;
     const float *feat = P.feat + c0;
     const float *feat_self = P.feat_self + c0;
     const int row = it.row;
-    const int pos = sl % HL;
     const int kk = 2 * (c0 / P.F);
 
     float sm = kNegBig, ss = 0.f;   // running softmax state of this lane's head (GAT)
@@ -342,9 +346,9 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
         float d = 0.f;
 #pragma unroll
         for (int v = 0; v < V4; ++v) {
-            att_s[v] = ld4(P.att_src + c0 + 4 * v);
-            h_self[v] = ld4(row_at(feat_self, row, P.ld_self) + 4 * v);
-            d += dot4(h_self[v], ld4(P.att_dst + c0 + 4 * v));
+            att_s[v] = ld4(P.att_src + c0 + CS * v);
+            h_self[v] = ld4(row_at(feat_self, row, P.ld_self) + CS * v);
+            d += dot4(h_self[v], ld4(P.att_dst + c0 + CS * v));
         }
         a_d = head_sum<HL>(d, lane, pos, HL, true);
     } else if (MODE == AGG_GCN) {
@@ -371,7 +375,7 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
             for (int u = 0; u < U; ++u) {
                 const float *p = row_at(feat, jj[u], P.ld_feat);
 #pragma unroll
-                for (int v = 0; v < V4; ++v) h[u][v] = ld4(p + 4 * v);
+                for (int v = 0; v < V4; ++v) h[u][v] = ld4(p + CS * v);
                 if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
             }
             if (MODE == AGG_GAT) {
@@ -440,8 +444,8 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
             const int nk = P.W / P.F;
             float *rec = P.partial + (size_t)it.slot * (size_t)(P.W + 2 * nk);
 #pragma unroll
-            for (int v = 0; v < V4; ++v) st4(rec + c0 + 4 * v, acc[v]);
-            if (MODE == AGG_GAT && c0 % P.F == 0) {
+            for (int v = 0; v < V4; ++v) st4(rec + c0 + CS * v, acc[v]);
+            if (MODE == AGG_GAT && pos == 0) {
                 rec[P.W + kk] = sm;
                 rec[P.W + kk + 1] = ss;
             }
@@ -470,7 +474,7 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
             }
         } else if (MODE == AGG_GCN) {
 #pragma unroll
-            for (int v = 0; v < V4; ++v) acc[v] = fma4(di * di, ld4(row_at(feat_self, row, P.ld_self) + 4 * v), acc[v]);
+            for (int v = 0; v < V4; ++v) acc[v] = fma4(di * di, ld4(row_at(feat_self, row, P.ld_self) + CS * v), acc[v]);
         }
     }
     if (sub == 0 && active) {
@@ -480,7 +484,7 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
 #pragma unroll
         for (int v = 0; v < V4; ++v) {   // finish_row per float4 chunk (stats are written by the head's first chunk)
             st.acc = acc[v];
-            finish_row<MODE>(P, row, c0 + 4 * v, it.end - it.beg, st, acc[v]);
+            finish_row<MODE>(P, row, c0 + CS * v, it.end - it.beg, st, acc[v]);
         }
     }
 }
@@ -763,10 +767,7 @@ int launch_fat(const AggLaunch &base, const int *sel, int n_sel, hipStream_t str
 
 template <int G, int MODE>
 int launch_fat_hl(const AggLaunch &base, int HL, const int *sel, int n, hipStream_t stream) {
-    if (MODE != AGG_GAT) return launch_fat<G, MODE, 1>(base, sel, n, stream);
     switch (HL) {
-        case 1: return launch_fat<G, MODE, 1>(base, sel, n, stream);
-        case 2: return launch_fat<G, MODE, 2>(base, sel, n, stream);
         case 4: return launch_fat<G, MODE, 4>(base, sel, n, stream);
         case 8: return launch_fat<G, MODE, (G >= 8 ? 8 : 1)>(base, sel, n, stream);
         default: return launch_fat<G, MODE, (G >= 16 ? 16 : 1)>(base, sel, n, stream);
@@ -786,12 +787,12 @@ int launch_fat_groups(AggLaunch &base, hipStream_t stream) {
         if (g.n_long <= 0 || g.hot_col) continue;
         const int G = fat_lanes(g.W);
         if (!G) continue;
-        int h = 1;
-        if (MODE == AGG_GAT) {
-            if (g.F % 16 != 0) continue;
-            h = g.F / 16;
-            if ((h & (h - 1)) != 0 || h > G) continue;   // whole heads on power-of-two lane groups
-        }
+        // whole heads on power-of-two lane groups of at least 4 lanes (F >= 64): below that a lane's chunks cannot be
+        // interleaved into 64-byte pieces (the 7 x 16-column last-layer group stays on the thin kernel)
+        const int F = MODE == AGG_GAT ? g.F : g.W;
+        if (F % 16 != 0) continue;
+        const int h = F / 16;
+        if ((h & (h - 1)) != 0 || h > G || h < 4) continue;
         lanes[i] = G;
         hl[i] = h;
     }

@@ -135,6 +135,7 @@ def test_lds_staged_hot_sources_are_bitwise_the_plain_kernel(kind, monkeypatch):
     result must be BITWISE the plain kernel's (PEA_HOT=0), on a graph with hub rows, multi-edges and every row bin."""
     from helpers import random_hin
     monkeypatch.setenv('PEA_HOT_MIN_EDGES', '1000')
+    monkeypatch.setenv('PEA_FAT', '0')      # compare like with like: the LDS variant is built on the thin (4 columns per lane) kernel
     n, blocks, rel = random_hin(17, n_user=6000, n_item=500, n_attr=30, e_u2i=150000, e_attr=2500)
     u2i, a2i = rel['u2i'], rel['a2i']
     flip = lambda e: np.ascontiguousarray(e[::-1])
@@ -161,3 +162,40 @@ def test_lds_staged_hot_sources_are_bitwise_the_plain_kernel(kind, monkeypatch):
     t_fused, t_stack = f64_forward(kind, sd, edges, steps, 1, 'att')
     assert_fp32_close(_np(hot_stack), wstack, t_stack, what='stack')
     assert_fused_close(_np(hot_fused), _np(hot_stack), want, t_fused, sd.get('att'))
+
+
+@pytest.mark.parametrize('kind', ['gat', 'gcn', 'sage'])
+def test_fat_lane_long_rows_match_the_thin_kernel_and_the_oracle(kind, monkeypatch):
+    """Groups whose heads are >= 64 columns wide run their long rows on the fat-lane kernel (16 columns per lane, chunks
+    of a head interleaved over its lanes; csrc/agg.hip: agg_long_fat_kernel).  Same edges, same order, same softmax
+    batches; only the grouping of columns inside a lane's dot product differs, so it agrees with the thin kernel
+    (PEA_FAT=0) to fp32 rounding and with the oracle to the usual tolerance -- on hub rows, multi-edges, 1 and 2 heads."""
+    from helpers import random_hin
+    n, blocks, rel = random_hin(19, n_user=5000, n_item=450, n_attr=30, e_u2i=120000, e_attr=2500)
+    u2i, a2i = rel['u2i'], rel['a2i']
+    flip = lambda e: np.ascontiguousarray(e[::-1])
+    edges = [[u2i, flip(u2i)], [a2i, flip(u2i)], [flip(u2i), u2i]]
+    steps = [2, 2, 2]
+    heads = 2 if kind == 'gat' else 1
+    model = build_model(kind, n, edges, steps, 64, 64, 16, heads=heads)
+    model.load_state_dict(random_state_dict(model, 13))
+    model.eval()
+    monkeypatch.setenv('PEA_FAT', '1')
+    names = _kernel_names_of_one_forward(model)
+    assert any(nm.startswith('agg_long_fat_') for nm in names), names
+    with torch.no_grad():
+        fat_fused, fat_stack = model.forward(return_stack=True)
+    monkeypatch.setenv('PEA_FAT', '0')
+    assert not any(nm.startswith('agg_long_fat_') for nm in _kernel_names_of_one_forward(model))
+    with torch.no_grad():
+        fused, stack = model.forward(return_stack=True)
+    scale = float(stack.abs().max())
+    assert float((fat_stack - stack).abs().max()) <= 2e-6 * scale
+    sd = {k: _np(v) for k, v in model.state_dict().items()}
+    cps = [[{k[len('pea_channels.%d.gnn_layers.%d.' % (p, s)):]: v for k, v in sd.items()
+             if k.startswith('pea_channels.%d.gnn_layers.%d.' % (p, s))} for s in range(2)] for p in range(3)]
+    hls = [[heads, 1]] * 3
+    want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, hls, att=sd.get('att'), return_stack=True)
+    t_fused, t_stack = f64_forward(kind, sd, edges, steps, heads, 'att')
+    assert_fp32_close(_np(fat_stack), wstack, t_stack, what='stack')
+    assert_fused_close(_np(fat_fused), _np(fat_stack), want, t_fused, sd.get('att'))
