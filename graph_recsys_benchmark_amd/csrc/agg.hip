@@ -722,11 +722,14 @@ int launch_g(const AggLaunch &base, int cls, const int *sel, int n, hipStream_t 
     return launch_for_g<G, MODE, 0>(base, sel, n, stream);
 }
 
-// ---- fat-lane long-row launches (16 columns per lane): groups of W >= 64, W % 16 == 0, whole heads per lane group
+// ---- fat-lane long-row launches: groups whose heads are 64, 128 or 256 columns wide.  A head is spread over HL >= 8
+// lanes so that one load instruction reads >= 128 contiguous bytes per edge (a whole cache line: with 4 lanes per head,
+// 64-byte pieces, the kernel touched every line twice and lost to the thin kernel): 8 columns per lane for F = 64,
+// 16 for F = 128 / 256.
 template <int MODE>
 const char *fat_name(int G) {
-    static char names[3][32];
-    const int i = G == 4 ? 0 : G == 8 ? 1 : 2;
+    static char names[4][32];
+    const int i = G == 8 ? 0 : G == 16 ? 1 : G == 32 ? 2 : 3;
     if (!names[i][0]) {
         const char *m = MODE == AGG_GAT ? "gat" : MODE == AGG_GCN ? "gcn" : "mean";
         snprintf(names[i], sizeof(names[i]), "agg_long_fat_g%d_%s", G, m);
@@ -734,14 +737,7 @@ const char *fat_name(int G) {
     return names[i];
 }
 
-inline int fat_lanes(int W) {  // lanes per edge at 16 columns per lane (4, 8 or 16), 0 = not eligible
-    if (W < 64 || W % 16 != 0 || W > 256) return 0;
-    int g = 4;
-    while (g * 16 < W) g <<= 1;
-    return g;
-}
-
-template <int G, int MODE, int HL>
+template <int G, int MODE, int HL, int V4>
 int launch_fat(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
     AggLaunch L;
     L.n_groups = 0;
@@ -760,18 +756,9 @@ int launch_fat(const AggLaunch &base, const int *sel, int n_sel, hipStream_t str
     L.blk_start[L.n_groups] = blocks;
     if (blocks <= 0) return PEA_OK;
     ProfScope ps(fat_name<MODE>(G), stream, alg, pull, table);
-    hipLaunchKernelGGL((agg_long_fat_kernel<G, MODE, HL, 4>), dim3(blocks), dim3(kBlock), 0, stream, L);
+    hipLaunchKernelGGL((agg_long_fat_kernel<G, MODE, HL, V4>), dim3(blocks), dim3(kBlock), 0, stream, L);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
-}
-
-template <int G, int MODE>
-int launch_fat_hl(const AggLaunch &base, int HL, const int *sel, int n, hipStream_t stream) {
-    switch (HL) {
-        case 4: return launch_fat<G, MODE, 4>(base, sel, n, stream);
-        case 8: return launch_fat<G, MODE, (G >= 8 ? 8 : 1)>(base, sel, n, stream);
-        default: return launch_fat<G, MODE, (G >= 16 ? 16 : 1)>(base, sel, n, stream);
-    }
 }
 
 // Launches the long items of every eligible group with the fat-lane kernel and marks those groups (skip_long).
@@ -780,35 +767,36 @@ int launch_fat_groups(AggLaunch &base, hipStream_t stream) {
     if (MODE == AGG_WSUM) return PEA_OK;
     const char *env = getenv("PEA_FAT");
     if (env && atoi(env) == 0) return PEA_OK;
-    int lanes[kMaxAggGroups], hl[kMaxAggGroups];
+    // (lanes per edge G, lanes per head HL, float4 chunks per lane V4) classes
+    const int classes[6][3] = {{8, 8, 2}, {16, 8, 2}, {32, 8, 2}, {8, 8, 4}, {16, 8, 4}, {16, 16, 4}};
+    int cls[kMaxAggGroups];
     for (int i = 0; i < base.n_groups; ++i) {
         const AggGroup &g = base.g[i];
-        lanes[i] = hl[i] = 0;
+        cls[i] = -1;
         if (g.n_long <= 0 || g.hot_col) continue;
-        const int G = fat_lanes(g.W);
-        if (!G) continue;
-        // whole heads on power-of-two lane groups of at least 4 lanes (F >= 64): below that a lane's chunks cannot be
-        // interleaved into 64-byte pieces (the 7 x 16-column last-layer group stays on the thin kernel)
-        const int F = MODE == AGG_GAT ? g.F : g.W;
-        if (F % 16 != 0) continue;
-        const int h = F / 16;
-        if ((h & (h - 1)) != 0 || h > G || h < 4) continue;
-        lanes[i] = G;
-        hl[i] = h;
+        const int F = MODE == AGG_GAT ? g.F : g.W;   // GCN / MEAN: the whole row is one "head"
+        if (g.W % F != 0 || g.W > 256) continue;
+        const int v4 = F == 64 ? 2 : (F == 128 || F == 256) ? 4 : 0;
+        if (!v4) continue;
+        const int hl = F / (4 * v4), G = g.W / (4 * v4);
+        for (int c = 0; c < 6; ++c)
+            if (classes[c][0] == G && classes[c][1] == hl && classes[c][2] == v4) cls[i] = c;
     }
-    for (int G = 4; G <= 16; G <<= 1)
-        for (int h = 1; h <= G; h <<= 1) {
-            int sel[kMaxAggGroups], n = 0;
-            for (int i = 0; i < base.n_groups; ++i)
-                if (lanes[i] == G && hl[i] == h) sel[n++] = i;
-            if (!n) continue;
-            switch (G) {
-                case 4: PEA_TRY((launch_fat_hl<4, MODE>(base, h, sel, n, stream))); break;
-                case 8: PEA_TRY((launch_fat_hl<8, MODE>(base, h, sel, n, stream))); break;
-                default: PEA_TRY((launch_fat_hl<16, MODE>(base, h, sel, n, stream))); break;
-            }
-            for (int q = 0; q < n; ++q) base.g[sel[q]].skip_long = 1;
+    for (int c = 0; c < 6; ++c) {
+        int sel[kMaxAggGroups], n = 0;
+        for (int i = 0; i < base.n_groups; ++i)
+            if (cls[i] == c) sel[n++] = i;
+        if (!n) continue;
+        switch (c) {
+            case 0: PEA_TRY((launch_fat<8, MODE, 8, 2>(base, sel, n, stream))); break;
+            case 1: PEA_TRY((launch_fat<16, MODE, 8, 2>(base, sel, n, stream))); break;
+            case 2: PEA_TRY((launch_fat<32, MODE, 8, 2>(base, sel, n, stream))); break;
+            case 3: PEA_TRY((launch_fat<8, MODE, 8, 4>(base, sel, n, stream))); break;
+            case 4: PEA_TRY((launch_fat<16, MODE, 8, 4>(base, sel, n, stream))); break;
+            default: PEA_TRY((launch_fat<16, MODE, 16, 4>(base, sel, n, stream))); break;
         }
+        for (int q = 0; q < n; ++q) base.g[sel[q]].skip_long = 1;
+    }
     return PEA_OK;
 }
 
