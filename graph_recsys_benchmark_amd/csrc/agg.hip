@@ -765,8 +765,11 @@ int launch_fat(const AggLaunch &base, const int *sel, int n_sel, hipStream_t str
 template <int MODE>
 int launch_fat_groups(AggLaunch &base, hipStream_t stream) {
     if (MODE == AGG_WSUM) return PEA_OK;
+    // OFF unless PEA_FAT=1: measured neutral to slower (round 2): 25m-shaped first-layer gather
+    // 0.534 vs 0.537 ms, Yelp SAGE long rows 0.075 vs 0.092 ms, stress 9-channel gather 3.98 vs 3.35 ms -- the thin kernel's
+    // 68-86 % VALU-busy overlaps its memory time, it is not the limiter.  Kept (and tested) as the record of that finding.
     const char *env = getenv("PEA_FAT");
-    if (env && atoi(env) == 0) return PEA_OK;
+    if (!(env && atoi(env) != 0)) return PEA_OK;
     // (lanes per edge G, lanes per head HL, float4 chunks per lane V4) classes
     const int classes[6][3] = {{8, 8, 2}, {16, 8, 2}, {32, 8, 2}, {8, 8, 4}, {16, 8, 4}, {16, 16, 4}};
     int cls[kMaxAggGroups];
