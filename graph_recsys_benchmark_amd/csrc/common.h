@@ -301,6 +301,32 @@ struct PackJob {
 constexpr int PEA_PACK_SAGE2 = 3;
 int launch_pack(const PackJob *jobs_host, int n_jobs, hipStream_t stream);
 
+// ---------------------------------------------------------------- two-step inference schedule, dense half (mlp2.hip)
+// T_1[n, c] = relu(in_c(n) . W0_c + b0_c) . W1_c for every 2-step channel c, in_c(n) = the first layer's aggregate of x
+// (A_0) or, for rows without incoming edges there, x[n] itself: both transforms of a channel chained in one kernel.
+constexpr int kMaxMlp2Chan = 32;   // the launch descriptor travels as a kernel argument (4 KB limit)
+struct Mlp2Chan {
+    const float *w0, *b0, *w1;            // first-layer weight / bias, second-layer weight (raw parameter tensors)
+    const float *att_src0, *att_dst0;     // GAT first layer: att_j, att_i [hid]
+    float *ws, *wd;                       // GAT: out: att vectors in x space, (W^T att) * log2(e)  [emb]
+    const unsigned char *deg0;            // [N] 1 = no incoming edge under the channel's first relation
+    const float *dinv;                    // GCN: deg^-1/2 of the first relation (node-indexed), else null
+    int a0_col, t1_col;                   // column of the channel in A_0 / T_1
+};
+struct Mlp2Launch {
+    int kind, n, emb, hid, out, per_pass;
+    const float *x;                       // [N, ldx]
+    const float *a0;                      // [N, ld_a0]
+    float *t1;                            // [N, ld_t1]
+    float *images;                        // [n][mlp2_image_bytes] packed weights (written by launch_mlp2_pack)
+    int64_t ldx, ld_a0, ld_t1;
+    Mlp2Chan c[kMaxMlp2Chan];
+};
+size_t mlp2_image_bytes(int emb, int hid);
+bool mlp2_supported(int emb, int hid, int out);
+int launch_mlp2_pack(const Mlp2Launch &L, hipStream_t stream);
+int launch_mlp2(const Mlp2Launch &L, const int *rows, int64_t n_rows, hipStream_t stream);
+
 // ---------------------------------------------------------------- fusion / scoring (fuse_score.hip)
 constexpr int kMaxChannels = 64;
 struct ChanCols {

@@ -1,0 +1,210 @@
+// Two-step inference schedule, dense half: for every node n and every 2-step channel c
+//     T_1[n, c] = relu( in_c(n) . W0_c + b0_c ) . W1_c            in_c(n) = A_0[n, c]  if n has incoming edges under the
+//                                                                            channel's first relation (the aggregate the
+//                                                                            first-layer gather wrote), else s_c(n) * x[n]
+// i.e. the first conv layer's transform (reference models/base.py:138: conv_0 = GATConv / GCNConv.lin, then F.relu) applied
+// AFTER the neighbour aggregation -- sum_j alpha_ij (W x_j) = W sum_j alpha_ij x_j, the reassociation SURVEY.md 8(a) A5
+// notes for SAGE, here for GAT (logits from x . (W^T att), mlp2_pack_kernel) and GCN -- chained with the second layer's
+// transform in ONE kernel: the [N, P * hidden] tables T_0 / O_0 of the level-wise schedule (630 MB each on the 25m-shaped
+// graph, written once and read once) are never materialised, x is the only gather source of the first layer, and a
+// sharded rank transforms exactly the rows it owns (x is replicated: no source-row redundancy).
+//
+// Per wave: 32 rows.  GEMM 1 (hidden^T = W0^T x^T) keeps the data row on the lane: v_mfma_f32_32x32x2_f32 with the weights
+// as the A operand and the row's inputs as B, so the accumulator tile [hidden unit][row] has its column (the data row) on
+// the lane and feeds GEMM 2 (out^T = W1^T hidden^T) as the B operand with no lane movement and no LDS (guide: "an
+// accumulator tile as the next MFMA's operand"): step (t, v) of GEMM 2 takes register v of tile t, bias + relu applied on
+// the way, against W1 rows laid out in the k order the accumulator registers carry (unit 32 t + (v & 3) + 8 (v >> 2) + 4 half).
+// fp32 products, fp32 accumulation (f32-input MFMA = an fmaf chain in k order): exact fp32 like the level-wise kernels.
+#include "common.h"
+
+namespace pea {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4m(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+constexpr float kLog2e = 1.44269504088896340736f;
+
+// image of one channel, in floats: [Wt0: HT * ET * 64 * 4][Wt1: HT * 4 * 64 * 4][b0p: 2 * HT * 16]
+__host__ __device__ inline int mlp2_image_floats(int ET, int HT) { return HT * ET * 256 + HT * 1024 + 2 * HT * 16; }
+
+// one block per channel: the LDS images of its two weight matrices + (GAT) the attention vectors in x space
+__global__ __launch_bounds__(256) void mlp2_pack_kernel(const Mlp2Launch L) {
+    const Mlp2Chan &C = L.c[blockIdx.x];
+    const int EMB = L.emb, HID = L.hid, OUT = L.out;
+    const int ET = EMB / 8, HT = HID / 32;
+    float *img = L.images + (size_t)blockIdx.x * mlp2_image_floats(ET, HT);
+    float *wt0 = img, *wt1 = img + HT * ET * 256, *b0p = wt1 + HT * 1024;
+    const bool gat = L.kind == PEA_KIND_GAT;
+    // W0(i, k): hidden unit i from input k.  GAT lin.weight is [HID, EMB] (out-major), GCN weight is [EMB, HID]
+    for (int idx = threadIdx.x; idx < HT * ET * 256; idx += 256) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % ET, t = (idx >> 8) / ET;
+        const int i = 32 * t + (lane & 31), k = 4 * (2 * q + (lane >> 5)) + e;
+        wt0[idx] = gat ? C.w0[(size_t)i * EMB + k] : C.w0[(size_t)k * HID + i];
+    }
+    // W1(j, i): output j from hidden unit i, rows >= OUT are zero.  GAT: [OUT, HID]; GCN: [HID, OUT]
+    for (int idx = threadIdx.x; idx < HT * 1024; idx += 256) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 3, t = idx >> 10;
+        const int j = lane & 31, i = 32 * t + 8 * g + 4 * (lane >> 5) + e;
+        wt1[idx] = j < OUT ? (gat ? C.w1[(size_t)j * HID + i] : C.w1[(size_t)i * OUT + j]) : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < 2 * HT * 16; idx += 256) {
+        const int v = idx & 15, t = (idx >> 4) % HT, half = (idx >> 4) / HT;
+        const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * half;
+        b0p[idx] = C.b0 ? C.b0[i] : 0.f;
+    }
+    if (gat) {
+        // logits of the first layer from x itself: (W x) . att = x . (W^T att); log2(e) folded in like the level-wise pack
+        for (int k = threadIdx.x; k < EMB; k += 256) {
+            float s = 0.f, d = 0.f;
+            for (int i = 0; i < HID; ++i) {
+                const float w = C.w0[(size_t)i * EMB + k];
+                s = fmaf(C.att_src0[i], w, s);
+                d = fmaf(C.att_dst0[i], w, d);
+            }
+            C.ws[k] = s * kLog2e;
+            C.wd[k] = d * kLog2e;
+        }
+    }
+}
+
+extern __shared__ float mlp2_lds[];
+
+template <int ET, int HT>
+__global__ __launch_bounds__(512) void mlp2_kernel(const Mlp2Launch L, const int *__restrict__ rows, int64_t n_rows) {
+    constexpr int IMG = HT * ET * 256 + HT * 1024 + 2 * HT * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r32 = lane & 31;
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    const int64_t wave_global = (int64_t)blockIdx.x * 8 + wave, n_waves = (int64_t)gridDim.x * 8;
+    for (int c0 = 0; c0 < L.n; c0 += L.per_pass) {
+        const int nc = min(L.per_pass, L.n - c0);
+        __syncthreads();
+        for (int idx = threadIdx.x * 4; idx < nc * IMG; idx += 512 * 4)   // IMG is a multiple of 4
+            *reinterpret_cast<float4 *>(mlp2_lds + idx) = ld4m(L.images + (size_t)c0 * IMG + idx);
+        __syncthreads();
+        for (int64_t tile = wave_global; tile < n_tiles; tile += n_waves) {
+            const int64_t q0 = tile * 32 + r32;
+            const bool valid = q0 < n_rows;
+            const int64_t row = valid ? (rows ? (int64_t)rows[q0] : q0) : 0;
+            for (int cc = 0; cc < nc; ++cc) {
+                const Mlp2Chan &C = L.c[c0 + cc];
+                const float *img = mlp2_lds + (size_t)cc * IMG;
+                const float *wt0 = img, *wt1 = img + HT * ET * 256, *b0p = wt1 + HT * 1024 + half * HT * 16;
+                // input row: the first layer's aggregate, or x itself where the row has no incoming edge there
+                const bool lone = C.deg0[row] != 0;
+                const float *src = lone ? L.x + row * L.ldx : L.a0 + row * L.ld_a0 + C.a0_col;
+                float sc = 1.f;
+                if (C.dinv && lone) {   // GCN: the self loop alone, norm = dinv_i^2
+                    const float di = C.dinv[row];
+                    sc = di * di;
+                }
+                float4 xa[ET];
+#pragma unroll
+                for (int q = 0; q < ET; ++q) {
+                    float4 t4 = ld4m(src + 4 * (2 * q + half));
+                    xa[q] = valid ? make_float4(sc * t4.x, sc * t4.y, sc * t4.z, sc * t4.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                f32x16 acc[HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+#pragma unroll
+                for (int q = 0; q < ET; ++q) {
+#pragma unroll
+                    for (int t = 0; t < HT; ++t) {
+                        const float4 w = ld4m(wt0 + ((size_t)(t * ET + q) * 64 + lane) * 4);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xa[q].x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xa[q].y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xa[q].z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xa[q].w, acc[t], 0, 0, 0);
+                    }
+                }
+                f32x16 out;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) out[v] = 0.f;
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 w = ld4m(wt1 + ((size_t)(t * 4 + g) * 64 + lane) * 4);
+                        const float4 b = ld4m(b0p + t * 16 + 4 * g);
+                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, fmaxf(acc[t][4 * g + 0] + b.x, 0.f), out, 0, 0, 0);
+                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, fmaxf(acc[t][4 * g + 1] + b.y, 0.f), out, 0, 0, 0);
+                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, fmaxf(acc[t][4 * g + 2] + b.z, 0.f), out, 0, 0, 0);
+                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, fmaxf(acc[t][4 * g + 3] + b.w, 0.f), out, 0, 0, 0);
+                    }
+                }
+                if (valid) {
+                    float *dst = L.t1 + row * L.ld_t1 + C.t1_col;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 = outputs 8g + 4 half .. + 3
+                        const int j0 = 8 * g + 4 * half;
+                        if (j0 < L.out)
+                            *reinterpret_cast<float4 *>(dst + j0) = make_float4(out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t mlp2_image_bytes(int emb, int hid) { return (size_t)mlp2_image_floats(emb / 8, hid / 32) * sizeof(float); }
+
+bool mlp2_supported(int emb, int hid, int out) {
+    return (emb == 64 || emb == 128) && (hid == 64 || hid == 128) && out >= 4 && out <= 32 && out % 4 == 0;
+}
+
+int launch_mlp2_pack(const Mlp2Launch &L, hipStream_t stream) {
+    ProfScope ps("pack_weights2", stream);
+    hipLaunchKernelGGL(mlp2_pack_kernel, dim3((unsigned)L.n), dim3(256), 0, stream, L);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+template <int ET, int HT>
+static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStream_t stream) {
+    constexpr size_t img = (size_t)(HT * ET * 256 + HT * 1024 + 2 * HT * 16) * sizeof(float);
+    constexpr size_t budget = 160 * 1024 - 2048;
+    L.per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)L.n, budget / img));
+    // even out the passes (9 channels at 6 per pass: 5 + 4 instead of 6 + 3)
+    const int passes = (L.n + L.per_pass - 1) / L.per_pass;
+    L.per_pass = (L.n + passes - 1) / passes;
+    const size_t lds = (size_t)L.per_pass * img;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp2_kernel<ET, HT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        lds_set = lds;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        PEA_HIP(hipGetDevice(&dev));
+        PEA_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+    }
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu, (n_tiles + 7) / 8));
+    const double flops = 2.0 * (double)n_rows * L.n * ((double)L.emb * L.hid + (double)L.hid * 32);
+    ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out), flops, 0.0);
+    hipLaunchKernelGGL((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(512), lds, stream, L, rows, n_rows);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
+int launch_mlp2(const Mlp2Launch &L, const int *rows, int64_t n_rows, hipStream_t stream) {
+    PEA_REQUIRE(mlp2_supported(L.emb, L.hid, L.out) && L.n > 0 && L.n <= kMaxMlp2Chan, PEA_ERR_ARG,
+                "mlp2: unsupported widths (%d, %d, %d) or %d channels", L.emb, L.hid, L.out, L.n);
+    if (n_rows <= 0) return PEA_OK;
+    if (L.emb == 64 && L.hid == 64) return launch_mlp2_v<8, 2>(L, rows, n_rows, stream);
+    if (L.emb == 64 && L.hid == 128) return launch_mlp2_v<8, 4>(L, rows, n_rows, stream);
+    if (L.emb == 128 && L.hid == 64) return launch_mlp2_v<16, 2>(L, rows, n_rows, stream);
+    return launch_mlp2_v<16, 4>(L, rows, n_rows, stream);
+}
+
+}  // namespace pea

@@ -70,6 +70,12 @@ struct pea_model {
     // SAGE without training buffers runs on the GAT/GCN schedule: transform first (mean_j(W x_j) = W mean_j(x_j)), so the
     // layers gather output-width rows; the root term lin_root(x_i) + bias is written first and the mean is added to it
     bool sage2 = false;
+    // GAT / GCN models of 2-step channels (every reference configuration) without training buffers run the TWO-STEP
+    // INFERENCE SCHEDULE: the first layer aggregates x itself (logits from x . (W^T att)), and ONE kernel applies both
+    // layers' transforms to the aggregate (csrc/mlp2.hip): T_0 / O_0 are never materialised.  PEA_FUSED2=0: level-wise.
+    bool fused2 = false;
+    int ld_a0 = 0;                        // row stride of A_0 (first-layer aggregates of x, P * emb columns), in the T_0 region
+    size_t mlp2_img_off = 0, mlp2_att_off = 0;   // floats from the pack base: weight images, x-space attention vectors
     const unsigned char *active_rows = nullptr;  // pea_model_set_active_rows: rows with a non-zero final-output gradient
     std::vector<int> reverse_of;          // relation -> index of the reversed relation in the plan (-1: absent)
     size_t off_dx = 0, off_gpack = 0, gpack_floats = 0, off_colsum = 0;

@@ -61,6 +61,15 @@ int build_schedule(pea_model *m) {
     const bool sage = d.kind == PEA_KIND_SAGE && !m->sage2, gat = d.kind == PEA_KIND_GAT;
     int Smax = 0;
     for (int p = 0; p < P; ++p) Smax = std::max(Smax, m->steps[(size_t)p]);
+    {
+        bool all2 = true;
+        for (int p = 0; p < P; ++p) all2 = all2 && m->steps[(size_t)p] == 2;
+        const char *env = getenv("PEA_FUSED2");
+        m->fused2 = all2 && !m->backward && !m->single_conv && (d.kind == PEA_KIND_GAT || d.kind == PEA_KIND_GCN) &&
+                    d.heads == 1 && P <= kMaxMlp2Chan && mlp2_supported(d.emb_dim, d.hidden_size, d.repr_dim) &&
+                    (plan->flags & PEA_PLAN_SELF_LOOPS) && !(env && atoi(env) == 0);
+        m->ld_a0 = pad_ld(P * d.emb_dim);
+    }
     m->levels.assign((size_t)Smax, Level());
     std::vector<int> in_w((size_t)P, d.emb_dim), in_col((size_t)P, 0);
     int x_cols = 0;
@@ -246,6 +255,11 @@ int build_schedule(pea_model *m) {
                 i = j;
             }
         }
+        if (m->fused2 && s == 0) {  // one aggregation group per channel, emb columns wide, one "head"
+            size_t p0 = 0;
+            for (const Unit &u : L.units) p0 += (size_t)slots_of(m, u.rel) * partial_record_floats(d.emb_dim, d.emb_dim);
+            partial = std::max(partial, p0);
+        }
         partial_max = std::max(partial_max, partial);
         if (plan->shard_world > 1 && s > 0) {
             for (GroupPlan &g : L.groups) {
@@ -255,7 +269,7 @@ int build_schedule(pea_model *m) {
             }
         }
         L.off_t = ws;
-        ws = pad_off(ws + (size_t)N * (size_t)L.ld_t);
+        ws = pad_off(ws + (size_t)N * (size_t)((m->fused2 && s == 0) ? std::max(L.ld_t, m->ld_a0) : L.ld_t));
         L.off_a = ws;
         L.off_o = ws;
         ws = pad_off(ws + (size_t)N * (size_t)L.ld_o);
@@ -263,9 +277,19 @@ int build_schedule(pea_model *m) {
             double cont_cols = 0.0;
             for (const Unit &u : L.units)
                 if (!u.last) cont_cols += u.HF;
-            m->compulsory_bytes += 8.0 * (double)N * L.n_cols + 8.0 * (double)N * cont_cols;
-            for (const GroupPlan &g : L.groups)
-                m->compulsory_bytes += 4.0 * (double)plan->rels[(size_t)g.rel].e_kept + 4.0 * ((double)N + 1.0);
+            if (m->fused2 && s == 0) {
+                // two-step schedule: no T_0 / O_0; per channel its index arrays and the aggregates A_0 of the rows that
+                // have incoming edges (written once, read once)
+                for (const Unit &u : L.units) {
+                    const Relation &R = plan->rels[(size_t)u.rel];
+                    const double rows_with_edges = (double)(R.n_short - R.n_short0) + R.n_direct + R.n_hub;
+                    m->compulsory_bytes += 4.0 * (double)R.e_kept + 4.0 * ((double)N + 1.0) + 8.0 * rows_with_edges * d.emb_dim;
+                }
+            } else {
+                m->compulsory_bytes += 8.0 * (double)N * L.n_cols + 8.0 * (double)N * cont_cols;
+                for (const GroupPlan &g : L.groups)
+                    m->compulsory_bytes += 4.0 * (double)plan->rels[(size_t)g.rel].e_kept + 4.0 * ((double)N + 1.0);
+            }
         }
         // statistics: messages and the algorithmic-byte yardstick of SURVEY.md 8(d)
         for (const Unit &u : L.units) {
@@ -281,6 +305,12 @@ int build_schedule(pea_model *m) {
                                 (gat ? 8.0 * Nn * u.heads : 0.0);
             }
         }
+    }
+    if (m->fused2) {
+        m->mlp2_img_off = pack;
+        pack = pad_off(pack + (size_t)P * (mlp2_image_bytes(d.emb_dim, d.hidden_size) / sizeof(float)));
+        m->mlp2_att_off = pack;
+        pack = pad_off(pack + (size_t)2 * P * (size_t)d.emb_dim);
     }
     m->ld_x = pad_ld(x_cols);
     m->alg_bytes += 4.0 * (double)N * P * d.repr_dim + 4.0 * (double)N * d.repr_dim;
@@ -747,6 +777,93 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         return launch_gemm_batch(jobs.data(), (int)jobs.size(), own_rows, n_own, stream);
     };
 
+    // ---- two-step inference schedule, stage 0: aggregate x per channel, then both transforms in one kernel -> T_1
+    auto run_fused2_stage0 = [&]() -> int {
+        Level &L0 = m->levels[0], &L1 = m->levels[1];
+        float *A0 = wsf + L0.off_t;
+        Mlp2Launch ML{};
+        ML.kind = kind;
+        ML.n = (int)L0.units.size();
+        ML.emb = d.emb_dim;
+        ML.hid = d.hidden_size;
+        ML.out = d.repr_dim;
+        ML.x = x;
+        ML.ldx = ldx;
+        ML.a0 = A0;
+        ML.ld_a0 = m->ld_a0;
+        ML.t1 = wsf + L1.off_t;
+        ML.ld_t1 = L1.ld_t;
+        ML.images = pack + m->mlp2_img_off;
+        const bool fc = d.gcn_deg_from_col != 0;
+        std::vector<AggGroup> gs;
+        size_t part_off = 0;
+        for (size_t ui = 0; ui < L0.units.size(); ++ui) {
+            const Unit &u = L0.units[ui];
+            const Unit *u1 = nullptr;
+            for (const Unit &c : L1.units)
+                if (c.p == u.p) u1 = &c;
+            PEA_REQUIRE(u1 != nullptr, PEA_ERR_ARG, "fused schedule: channel %d has no second layer", u.p);
+            Relation &R = plan->rels[(size_t)u.rel];
+            Mlp2Chan &C = ML.c[ui];
+            C.w0 = param(u, 0);
+            C.w1 = param(*u1, 0);
+            PEA_REQUIRE(C.w0 && C.w1, PEA_ERR_ARG, "forward: null weight pointer (channel %d)", u.p);
+            C.ws = pack + m->mlp2_att_off + (size_t)2 * ui * d.emb_dim;
+            C.wd = C.ws + d.emb_dim;
+            C.a0_col = (int)ui * d.emb_dim;
+            C.t1_col = u1->t_col;
+            C.deg0 = R.deg0;
+            if (kind == PEA_KIND_GAT) {
+                C.att_dst0 = param(u, 1);   // att_i multiplies the TARGET row
+                C.att_src0 = param(u, 2);   // att_j multiplies the SOURCE row
+                C.b0 = param(u, 3);
+                PEA_REQUIRE(C.att_src0 && C.att_dst0, PEA_ERR_ARG, "forward: null att_i/att_j (channel %d)", u.p);
+            } else {
+                C.b0 = param(u, 1);
+                PEA_TRY(ensure_dinv(plan, u.rel, fc, stream));
+                C.dinv = fc ? R.dinv_col : R.dinv_row;
+            }
+            // the channel's first-layer aggregation of x: rows without incoming edges are not visited (mlp2 reads x)
+            AggGroup a{};
+            a.rowptr = R.rowptr;
+            a.col = R.col;
+            a.short_rows = R.short_rows + R.n_short0;
+            a.n_short = R.n_short - R.n_short0;
+            a.long_items = R.long_items;
+            a.n_long = R.n_long;
+            a.hub_rows = R.hub_rows;
+            a.hub_first = R.hub_first;
+            a.hub_count = R.hub_count;
+            a.n_hub = R.n_hub;
+            a.W = d.emb_dim;
+            a.F = d.emb_dim;
+            a.feat = x;
+            a.ld_feat = (int)ldx;
+            a.feat_self = x;
+            a.ld_self = (int)ldx;
+            a.att_src = C.ws;
+            a.att_dst = C.wd;
+            a.out = A0 + C.a0_col;
+            a.ld_out = m->ld_a0;
+            a.self_loop = 1;
+            a.neg_slope = d.negative_slope;
+            a.partial = partial + part_off;
+            part_off += (size_t)slots_of(m, u.rel) * partial_record_floats(d.emb_dim, d.emb_dim);
+            a.dinv = C.dinv;
+            a.dinv_self = C.dinv;
+            a.msgs_short = (double)R.edges_short + a.n_short;
+            a.msgs_long = (double)R.edges_long + R.n_direct;
+            a.idx_share = 1.0;
+            a.table_rows = (double)R.src_span;
+            gs.push_back(a);
+        }
+        PEA_TRY(launch_mlp2_pack(ML, stream));
+        const AggMode mode = kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN;
+        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+            PEA_TRY(launch_aggregate(mode, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        return launch_mlp2(ML, own_rows, n_own, stream);
+    };
+
     // Stage k = the work between two exchanges of gather sources (all stages back to back when not sharded):
     //   GAT/GCN: [k == 0: pack, transform_0]  aggregate_k  [transform_{k+1}]        SAGE: [pack]  aggregate_k  transform_k
     // After stage k < last, the gather source of level k+1 is complete on its owner rows (T_{k+1} resp. O_k).
@@ -754,7 +871,10 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
     PEA_REQUIRE(s_beg >= 0 && s_end <= n_levels, PEA_ERR_ARG, "forward: stage %d of %d", stage, n_levels);
     for (int k = s_beg; k < s_end; ++k) {
         if (k == 0) PEA_TRY(pack_weights());
-        if (kind == PEA_KIND_SAGE && !m->sage2) {
+        if (m->fused2 && !training) {
+            if (k == 0) PEA_TRY(run_fused2_stage0());
+            else PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
+        } else if (kind == PEA_KIND_SAGE && !m->sage2) {
             PEA_TRY(run_groups(k, AGG_MEAN));
             PEA_TRY(run_gemm(k));
         } else {
