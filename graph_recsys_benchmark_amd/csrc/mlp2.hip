@@ -71,6 +71,39 @@ __global__ __launch_bounds__(256) void mlp2_pack_kernel(const Mlp2Launch L) {
 
 extern __shared__ float mlp2_lds[];
 
+// one work item = (32-row tile, channel of the resident pass); consecutive waves take the channels of one tile (its x rows
+// stay in L1), items are dealt round-robin over all waves of the grid (balanced to one item), and the input rows of the
+// NEXT item are loaded before the current item's MFMA chains start
+template <int ET>
+struct Mlp2In {
+    float4 xa[ET];
+    int64_t row;
+    bool valid;
+};
+
+template <int ET>
+__device__ __forceinline__ void mlp2_load(const Mlp2Launch &L, const int *rows, int64_t n_rows, int64_t tile, int ch, int r32,
+                                          int half, Mlp2In<ET> &in) {
+    const Mlp2Chan &C = L.c[ch];
+    const int64_t q0 = tile * 32 + r32;
+    in.valid = q0 < n_rows;
+    in.row = in.valid ? (rows ? (int64_t)rows[q0] : q0) : 0;
+    // input row: the first layer's aggregate, or x itself where the row has no incoming edge there
+    const bool lone = C.deg0[in.row] != 0;
+    const float *src = lone ? L.x + in.row * L.ldx : L.a0 + in.row * L.ld_a0 + C.a0_col;
+    float sc = 1.f;
+    if (C.dinv && lone) {   // GCN: the self loop alone, norm = dinv_i^2
+        const float di = C.dinv[in.row];
+        sc = di * di;
+    }
+    if (!in.valid) sc = 0.f;
+#pragma unroll
+    for (int q = 0; q < ET; ++q) {
+        const float4 t4 = ld4m(src + 4 * (2 * q + half));
+        in.xa[q] = make_float4(sc * t4.x, sc * t4.y, sc * t4.z, sc * t4.w);
+    }
+}
+
 template <int ET, int HT>
 __global__ __launch_bounds__(512) void mlp2_kernel(const Mlp2Launch L, const int *__restrict__ rows, int64_t n_rows) {
     constexpr int IMG = HT * ET * 256 + HT * 1024 + 2 * HT * 16;
@@ -83,69 +116,57 @@ __global__ __launch_bounds__(512) void mlp2_kernel(const Mlp2Launch L, const int
         for (int idx = threadIdx.x * 4; idx < nc * IMG; idx += 512 * 4)   // IMG is a multiple of 4
             *reinterpret_cast<float4 *>(mlp2_lds + idx) = ld4m(L.images + (size_t)c0 * IMG + idx);
         __syncthreads();
-        for (int64_t tile = wave_global; tile < n_tiles; tile += n_waves) {
-            const int64_t q0 = tile * 32 + r32;
-            const bool valid = q0 < n_rows;
-            const int64_t row = valid ? (rows ? (int64_t)rows[q0] : q0) : 0;
-            for (int cc = 0; cc < nc; ++cc) {
-                const Mlp2Chan &C = L.c[c0 + cc];
-                const float *img = mlp2_lds + (size_t)cc * IMG;
-                const float *wt0 = img, *wt1 = img + HT * ET * 256, *b0p = wt1 + HT * 1024 + half * HT * 16;
-                // input row: the first layer's aggregate, or x itself where the row has no incoming edge there
-                const bool lone = C.deg0[row] != 0;
-                const float *src = lone ? L.x + row * L.ldx : L.a0 + row * L.ld_a0 + C.a0_col;
-                float sc = 1.f;
-                if (C.dinv && lone) {   // GCN: the self loop alone, norm = dinv_i^2
-                    const float di = C.dinv[row];
-                    sc = di * di;
-                }
-                float4 xa[ET];
+        const int64_t n_items = n_tiles * nc;
+        Mlp2In<ET> cur, nxt;
+        if (wave_global < n_items) mlp2_load<ET>(L, rows, n_rows, wave_global / nc, c0 + (int)(wave_global % nc), r32, half, cur);
+        for (int64_t item = wave_global; item < n_items; item += n_waves) {
+            const int cc = (int)(item % nc);
+            const int64_t item2 = item + n_waves;
+            if (item2 < n_items) mlp2_load<ET>(L, rows, n_rows, item2 / nc, c0 + (int)(item2 % nc), r32, half, nxt);
+            const Mlp2Chan &C = L.c[c0 + cc];
+            const float *img = mlp2_lds + (size_t)cc * IMG;
+            const float *wt0 = img, *wt1 = img + HT * ET * 256, *b0p = wt1 + HT * 1024 + half * HT * 16;
+            f32x16 acc[HT];
 #pragma unroll
-                for (int q = 0; q < ET; ++q) {
-                    float4 t4 = ld4m(src + 4 * (2 * q + half));
-                    xa[q] = valid ? make_float4(sc * t4.x, sc * t4.y, sc * t4.z, sc * t4.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                f32x16 acc[HT];
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
-                for (int t = 0; t < HT; ++t)
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-#pragma unroll
-                for (int q = 0; q < ET; ++q) {
-#pragma unroll
-                    for (int t = 0; t < HT; ++t) {
-                        const float4 w = ld4m(wt0 + ((size_t)(t * ET + q) * 64 + lane) * 4);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xa[q].x, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xa[q].y, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xa[q].z, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xa[q].w, acc[t], 0, 0, 0);
-                    }
-                }
-                f32x16 out;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) out[v] = 0.f;
+            for (int q = 0; q < ET; ++q) {
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 w = ld4m(wt1 + ((size_t)(t * 4 + g) * 64 + lane) * 4);
-                        const float4 b = ld4m(b0p + t * 16 + 4 * g);
-                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, fmaxf(acc[t][4 * g + 0] + b.x, 0.f), out, 0, 0, 0);
-                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, fmaxf(acc[t][4 * g + 1] + b.y, 0.f), out, 0, 0, 0);
-                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, fmaxf(acc[t][4 * g + 2] + b.z, 0.f), out, 0, 0, 0);
-                        out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, fmaxf(acc[t][4 * g + 3] + b.w, 0.f), out, 0, 0, 0);
-                    }
-                }
-                if (valid) {
-                    float *dst = L.t1 + row * L.ld_t1 + C.t1_col;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 = outputs 8g + 4 half .. + 3
-                        const int j0 = 8 * g + 4 * half;
-                        if (j0 < L.out)
-                            *reinterpret_cast<float4 *>(dst + j0) = make_float4(out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]);
-                    }
+                    const float4 w = ld4m(wt0 + ((size_t)(t * ET + q) * 64 + lane) * 4);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, cur.xa[q].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, cur.xa[q].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, cur.xa[q].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, cur.xa[q].w, acc[t], 0, 0, 0);
                 }
             }
+            f32x16 out;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) out[v] = 0.f;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 w = ld4m(wt1 + ((size_t)(t * 4 + g) * 64 + lane) * 4);
+                    const float4 b = ld4m(b0p + t * 16 + 4 * g);
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, fmaxf(acc[t][4 * g + 0] + b.x, 0.f), out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, fmaxf(acc[t][4 * g + 1] + b.y, 0.f), out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, fmaxf(acc[t][4 * g + 2] + b.z, 0.f), out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, fmaxf(acc[t][4 * g + 3] + b.w, 0.f), out, 0, 0, 0);
+                }
+            }
+            if (cur.valid) {
+                float *dst = L.t1 + cur.row * L.ld_t1 + C.t1_col;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 = outputs 8g + 4 half .. + 3
+                    const int j0 = 8 * g + 4 * half;
+                    if (j0 < L.out)
+                        *reinterpret_cast<float4 *>(dst + j0) = make_float4(out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]);
+                }
+            }
+            cur = nxt;
         }
     }
 }
