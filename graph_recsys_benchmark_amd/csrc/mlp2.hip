@@ -70,6 +70,12 @@ __global__ __launch_bounds__(256) void mlp2_pack_kernel(const Mlp2Launch L) {
 }
 
 extern __shared__ float mlp2_lds[];
+// workgroup size: 1024 threads (16 waves per CU: one workgroup, the weight images fill the LDS) where 128 registers per
+// lane suffice (emb = hidden = 64), else 512
+template <int ET, int HT>
+struct Mlp2Cfg {
+    static constexpr int kThreads = (ET == 8 && HT == 2) ? 1024 : 512;
+};
 
 // one work item = (32-row tile, channel of the resident pass); consecutive waves take the channels of one tile (its x rows
 // stay in L1), items are dealt round-robin over all waves of the grid (balanced to one item), and the input rows of the
@@ -105,15 +111,17 @@ __device__ __forceinline__ void mlp2_load(const Mlp2Launch &L, const int *rows, 
 }
 
 template <int ET, int HT>
-__global__ __launch_bounds__(512) void mlp2_kernel(const Mlp2Launch L, const int *__restrict__ rows, int64_t n_rows) {
+__global__ __launch_bounds__(Mlp2Cfg<ET, HT>::kThreads) void mlp2_kernel(const Mlp2Launch L, const int *__restrict__ rows, int64_t n_rows) {
     constexpr int IMG = HT * ET * 256 + HT * 1024 + 2 * HT * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r32 = lane & 31;
     const int64_t n_tiles = (n_rows + 31) / 32;
-    const int64_t wave_global = (int64_t)blockIdx.x * 8 + wave, n_waves = (int64_t)gridDim.x * 8;
+    constexpr int kMlp2Threads = Mlp2Cfg<ET, HT>::kThreads;
+    constexpr int WPB = kMlp2Threads / 64;
+    const int64_t wave_global = (int64_t)blockIdx.x * WPB + wave, n_waves = (int64_t)gridDim.x * WPB;
     for (int c0 = 0; c0 < L.n; c0 += L.per_pass) {
         const int nc = min(L.per_pass, L.n - c0);
         __syncthreads();
-        for (int idx = threadIdx.x * 4; idx < nc * IMG; idx += 512 * 4)   // IMG is a multiple of 4
+        for (int idx = threadIdx.x * 4; idx < nc * IMG; idx += kMlp2Threads * 4)   // IMG is a multiple of 4
             *reinterpret_cast<float4 *>(mlp2_lds + idx) = ld4m(L.images + (size_t)c0 * IMG + idx);
         __syncthreads();
         const int64_t n_items = n_tiles * nc;
@@ -210,10 +218,11 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
         n_cu = prop.multiProcessorCount;
     }
     const int64_t n_tiles = (n_rows + 31) / 32;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu, (n_tiles + 7) / 8));
+    constexpr int kMlp2Threads = Mlp2Cfg<ET, HT>::kThreads;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu, (n_tiles * L.per_pass + 15) / 16));
     const double flops = 2.0 * (double)n_rows * L.n * ((double)L.emb * L.hid + (double)L.hid * 32);
     ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out), flops, 0.0);
-    hipLaunchKernelGGL((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(512), lds, stream, L, rows, n_rows);
+    hipLaunchKernelGGL((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
