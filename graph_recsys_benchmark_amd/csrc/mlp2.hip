@@ -111,7 +111,7 @@ __device__ __forceinline__ void mlp2_load(const Mlp2Launch &L, const int *rows, 
 }
 
 template <int ET, int HT>
-__global__ __launch_bounds__(Mlp2Cfg<ET, HT>::kThreads) void mlp2_kernel(const Mlp2Launch L, const int *__restrict__ rows, int64_t n_rows) {
+__global__ __launch_bounds__((Mlp2Cfg<ET, HT>::kThreads)) void mlp2_kernel(const Mlp2Launch L, const int *__restrict__ rows, int64_t n_rows) {
     constexpr int IMG = HT * ET * 256 + HT * 1024 + 2 * HT * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r32 = lane & 31;
     const int64_t n_tiles = (n_rows + 31) / 32;
