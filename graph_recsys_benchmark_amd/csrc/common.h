@@ -315,6 +315,10 @@ struct Mlp2Chan {
 };
 struct Mlp2Launch {
     int kind, n, emb, hid, out, per_pass;
+    // channel groups (what fits the LDS together) run side by side: workgroups [blk_start[g], blk_start[g + 1]) keep the
+    // images of channels [g * per_pass, ...) resident and share that group's (tile, channel) items
+    int n_groups;
+    int blk_start[kMaxMlp2Chan + 1];
     const float *x;                       // [N, ldx]
     const float *a0;                      // [N, ld_a0]
     float *t1;                            // [N, ld_t1]

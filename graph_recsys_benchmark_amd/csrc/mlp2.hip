@@ -117,10 +117,13 @@ __global__ __launch_bounds__((Mlp2Cfg<ET, HT>::kThreads)) void mlp2_kernel(const
     const int64_t n_tiles = (n_rows + 31) / 32;
     constexpr int kMlp2Threads = Mlp2Cfg<ET, HT>::kThreads;
     constexpr int WPB = kMlp2Threads / 64;
-    const int64_t wave_global = (int64_t)blockIdx.x * WPB + wave, n_waves = (int64_t)gridDim.x * WPB;
-    for (int c0 = 0; c0 < L.n; c0 += L.per_pass) {
+    int grp = 0;
+    while (grp + 1 < L.n_groups && (int)blockIdx.x >= L.blk_start[grp + 1]) ++grp;
+    const int64_t wave_global = (int64_t)((int)blockIdx.x - L.blk_start[grp]) * WPB + wave;
+    const int64_t n_waves = (int64_t)(L.blk_start[grp + 1] - L.blk_start[grp]) * WPB;
+    {
+        const int c0 = grp * L.per_pass;
         const int nc = min(L.per_pass, L.n - c0);
-        __syncthreads();
         for (int idx = threadIdx.x * 4; idx < nc * IMG; idx += kMlp2Threads * 4)   // IMG is a multiple of 4
             *reinterpret_cast<float4 *>(mlp2_lds + idx) = ld4m(L.images + (size_t)c0 * IMG + idx);
         __syncthreads();
@@ -219,7 +222,19 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
     }
     const int64_t n_tiles = (n_rows + 31) / 32;
     constexpr int kMlp2Threads = Mlp2Cfg<ET, HT>::kThreads;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu, (n_tiles * L.per_pass + 15) / 16));
+    constexpr int WPB = kMlp2Threads / 64;
+    // workgroups per channel group in proportion to its channels; no more than its items can feed
+    L.n_groups = passes;
+    int blocks = 0;
+    for (int g = 0; g < passes; ++g) {
+        const int nc = std::min(L.per_pass, L.n - g * L.per_pass);
+        int64_t want = std::max<int64_t>(1, ((int64_t)n_cu * nc + L.n / 2) / L.n);
+        want = std::min<int64_t>(want, std::max<int64_t>(1, (n_tiles * nc + WPB - 1) / WPB));
+        L.blk_start[g] = blocks;
+        blocks += (int)want;
+    }
+    L.blk_start[passes] = blocks;
+    const int grid = blocks;
     const double flops = 2.0 * (double)n_rows * L.n * ((double)L.emb * L.hid + (double)L.hid * 32);
     ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out), flops, 0.0);
     hipLaunchKernelGGL((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
