@@ -245,6 +245,15 @@ def kernel_roofline(name, rec, traffic_tab, flops):
     return out
 
 
+def transform_flops(sp, n, steps):
+    """Useful flops of the dense transforms of a 2-step GAT / GCN model over `steps` steps, by kernel name: the level-wise
+    schedule's two launches (PEA_FUSED2=0) or the two-step schedule's one (csrc/mlp2.hip: both layers chained; the
+    padding of the second product to 32 output rows is not counted)."""
+    l0 = 2.0 * n * sp['emb_dim'] * sp['hidden_size'] * sp['num_metapaths'] * steps
+    l1 = 2.0 * n * sp['hidden_size'] * sp['repr_dim'] * sp['num_metapaths'] * steps
+    return {'gemm_mfma_shared': l0, 'gemm_mfma_narrow': l1, 'mlp2_fused': l0 + l1}
+
+
 def single_gpu_schedule(world, args):
     return world == 1 and args.emulate_world <= 1
 
@@ -389,8 +398,7 @@ def main():
         flops = {}
         if args.kind in ('gat', 'gcn') and single_gpu_schedule(world, args):     # the two transform launches of a 2-step model
             sp, n = dataset.spec, dataset.num_nodes
-            flops = {'gemm_mfma_shared': 2.0 * n * sp['emb_dim'] * sp['hidden_size'] * sp['num_metapaths'] * args.steps,
-                     'gemm_mfma_narrow': 2.0 * n * sp['hidden_size'] * sp['repr_dim'] * sp['num_metapaths'] * args.steps}
+            flops = transform_flops(sp, n, args.steps)
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         out['roofline'] = kernel_roofline(dom[0], dom[1], traffic_tab, flops)
         gathers = {k: v for k, v in prof.items() if v[3] > 0}
@@ -512,8 +520,7 @@ def hbm_resident_leg(args, device, timed_region, with_check, scale=0.3):
     sp, n = ds.spec, ds.num_nodes
     flops = {}
     if args.kind in ('gat', 'gcn'):
-        flops = {'gemm_mfma_shared': 2.0 * n * sp['emb_dim'] * sp['hidden_size'] * sp['num_metapaths'] * steps,
-                 'gemm_mfma_narrow': 2.0 * n * sp['hidden_size'] * sp['repr_dim'] * sp['num_metapaths'] * steps}
+        flops = transform_flops(sp, n, steps)
     tab = load_traffic('stress_10m', args.kind, scale, 1)
     dom = max(prof.items(), key=lambda kv: kv[1][1])
     gathers = {k: v for k, v in prof.items() if v[3] > 0}

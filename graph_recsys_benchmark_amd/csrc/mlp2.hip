@@ -235,8 +235,7 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
     }
     L.blk_start[passes] = blocks;
     const int grid = blocks;
-    const double flops = 2.0 * (double)n_rows * L.n * ((double)L.emb * L.hid + (double)L.hid * 32);
-    ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out), flops, 0.0);
+    ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out));
     hipLaunchKernelGGL((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
