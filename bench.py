@@ -186,32 +186,46 @@ def cpu_baseline(dataset, model, kind, samples):
 def load_traffic(preset, kind, scale, world):
     """{kernel: {hbm_bytes_per_launch, l2_hit_rate, ...}} measured with rocprofv3 PMC passes for THIS preset / kind / scale
     on one GPU (profiles/traffic.json, written by profiles/summarize.py; key '<preset>/<kind>' at full scale,
-    '<preset>@<scale>/<kind>' otherwise), or {}."""
-    if world != 1:
-        return {}
+    '<preset>@<scale>/<kind>' otherwise), or {}.  A rank of a sharded run gathers from the SAME source table through the
+    same source slices (rows are sharded, sources are not), so it takes the L2 hit rate of the one-GPU profile to name
+    the cache tier -- marked as such -- and no byte counts (those are per whole-graph launch)."""
     key = '%s/%s' % (preset, kind) if scale == 1.0 else '%s@%g/%s' % (preset, scale, kind)
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            return json.load(f).get(key, {})
+            tab = json.load(f).get(key, {})
     except Exception:
         return {}
+    if world == 1:
+        return tab
+    return {k: {'l2_hit_rate': v.get('l2_hit_rate'), 'hit_from': 'the one-GPU profile of this preset'}
+            for k, v in tab.items() if isinstance(v, dict) and v.get('l2_hit_rate') is not None}
 
 
-def gather_tier(table_bytes, l2_hit_rate):
+def gather_tier(table_bytes, l2_hit_rate, achieved=None, hit_from=None):
     """(tier name, ceiling in GB/s, how it was decided) of a row gather.  With a measured L2 hit rate h of the kernel:
     h >= 0.5 -> the XCD L2s serve most rows: the guide's L2-resident ceiling; h < 0.5 -> mixed: the harmonic blend of the
     L2 ceiling (share h) and the ceiling of where the misses go (Infinity Cache while the table fits its 256 MiB, else
-    HBM).  Without a PMC profile for this preset / kind: from the table's footprint alone."""
+    HBM).  Without a PMC profile for this preset / kind: from the table's footprint alone -- unless the measured rate is
+    above that tier's ceiling, which proves the rows come from a faster tier (the plans slice the sources so that a
+    slice's rows stay in L2): then the next tier up is the bound."""
     below = 'infinity_cache' if table_bytes <= MALL_BYTES else 'hbm'
     if l2_hit_rate is not None:
+        src = 'measured L2 hit rate %.2f' % l2_hit_rate + (' (%s)' % hit_from if hit_from else '')
         if l2_hit_rate >= 0.5:
-            return 'l2', GATHER_CEILING_GBS['l2'], 'measured L2 hit rate %.2f' % l2_hit_rate
+            return 'l2', GATHER_CEILING_GBS['l2'], src
         blend = 1.0 / (l2_hit_rate / GATHER_CEILING_GBS['l2'] + (1.0 - l2_hit_rate) / GATHER_CEILING_GBS[below])
-        return 'l2+' + below, blend, ('measured L2 hit rate %.2f, table %.0f MB: harmonic blend of the L2 and %s gather '
-                                      'ceilings' % (l2_hit_rate, table_bytes / 1e6, below))
+        return 'l2+' + below, blend, ('%s, table %.0f MB: harmonic blend of the L2 and %s gather ceilings'
+                                      % (src, table_bytes / 1e6, below))
     if table_bytes <= L2_BYTES // 8:
         return 'l2', GATHER_CEILING_GBS['l2'], 'table %.1f MB fits one XCD L2 (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
-    return below, GATHER_CEILING_GBS[below], 'table %.0f MB vs the 256 MiB Infinity Cache (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
+    order = ['hbm', 'infinity_cache', 'l2']
+    tier, why = below, 'table %.0f MB vs the 256 MiB Infinity Cache (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
+    while achieved is not None and achieved > GATHER_CEILING_GBS[tier] and tier != 'l2':
+        nxt = order[order.index(tier) + 1]
+        why += '; measured %.0f GB/s is above the %s gather ceiling, so the sliced sources are served from %s' % (
+            achieved, tier, nxt)
+        tier = nxt
+    return tier, GATHER_CEILING_GBS[tier], why
 
 
 def kernel_roofline(name, rec, traffic_tab, flops):
@@ -227,8 +241,8 @@ def kernel_roofline(name, rec, traffic_tab, flops):
                    definition='2*rows*K*n_out flops of the launches / their time; peak = fp32-input MFMA '
                               '(v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s, MI355X_MICROARCH.md)')
     elif pulled > 0:                                         # neighbour aggregation: a row gather
-        tier, peak, why = gather_tier(table, hit)
         achieved = pulled / launches / avg_s / 1e9
+        tier, peak, why = gather_tier(table, hit, achieved, meas.get('hit_from'))
         out.update(bound='hbm', achieved=achieved, peak=peak, unit='GB/s', frac=achieved / peak, tier=tier, tier_from=why,
                    gather_table_bytes=table, gathered_bytes_per_launch=pulled / launches,
                    definition='achieved = (4*W row bytes + 4 index bytes) x messages of the launch / avg launch time; peak '
@@ -394,7 +408,7 @@ def main():
         'reference_yardstick': {'algorithmic_bytes_per_step': alg_bytes, 'GBs': alg_bytes / step_s / 1e9},
     }
     if prof:
-        traffic_tab = {} if args.emulate_world else load_traffic(args.preset, args.kind, args.scale, world)
+        traffic_tab = load_traffic(args.preset, args.kind, args.scale, max(world, args.emulate_world or 1))
         flops = {}
         if args.kind in ('gat', 'gcn') and single_gpu_schedule(world, args):     # the two transform launches of a 2-step model
             sp, n = dataset.spec, dataset.num_nodes
