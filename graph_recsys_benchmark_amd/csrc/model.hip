@@ -80,6 +80,8 @@ int build_schedule(pea_model *m) {
     // once (however often its rows are gathered afterwards: re-reads can come from cache), O_s of the channels that
     // continue written once and read once, every group's index arrays read once; X written and read once; the fused
     // table written once.  step time x 8 TB/s over this = how far the whole step is from the DRAM floor.
+    // A rank of a sharded plan writes and reads its own rows only (x is replicated: read whole).
+    const double Nr = (plan->shard_world > 1 && plan->n_owned > 0) ? (double)plan->n_owned : (double)N;
     m->compulsory_bytes = 4.0 * (double)N * d.emb_dim;
 
     for (int s = 0; s < Smax; ++s) {
@@ -283,12 +285,12 @@ int build_schedule(pea_model *m) {
                 for (const Unit &u : L.units) {
                     const Relation &R = plan->rels[(size_t)u.rel];
                     const double rows_with_edges = (double)(R.n_short - R.n_short0) + R.n_direct + R.n_hub;
-                    m->compulsory_bytes += 4.0 * (double)R.e_kept + 4.0 * ((double)N + 1.0) + 8.0 * rows_with_edges * d.emb_dim;
+                    m->compulsory_bytes += 4.0 * (double)R.e_kept + 4.0 * (Nr + 1.0) + 8.0 * rows_with_edges * d.emb_dim;
                 }
             } else {
-                m->compulsory_bytes += 8.0 * (double)N * L.n_cols + 8.0 * (double)N * cont_cols;
+                m->compulsory_bytes += 8.0 * Nr * L.n_cols + 8.0 * Nr * cont_cols;
                 for (const GroupPlan &g : L.groups)
-                    m->compulsory_bytes += 4.0 * (double)plan->rels[(size_t)g.rel].e_kept + 4.0 * ((double)N + 1.0);
+                    m->compulsory_bytes += 4.0 * (double)plan->rels[(size_t)g.rel].e_kept + 4.0 * (Nr + 1.0);
             }
         }
         // statistics: messages and the algorithmic-byte yardstick of SURVEY.md 8(d)
@@ -314,7 +316,7 @@ int build_schedule(pea_model *m) {
     }
     m->ld_x = pad_ld(x_cols);
     m->alg_bytes += 4.0 * (double)N * P * d.repr_dim + 4.0 * (double)N * d.repr_dim;
-    m->compulsory_bytes += 8.0 * (double)N * x_cols + 4.0 * (double)N * d.repr_dim;
+    m->compulsory_bytes += 8.0 * Nr * x_cols + 4.0 * Nr * d.repr_dim;
     m->pack_floats = pad_off(pack);
     size_t off = m->pack_floats;
     for (Level &L : m->levels) {
