@@ -50,10 +50,8 @@ __device__ __forceinline__ void finish_row(const AggGroup &P, int row, int c4, i
 // short rows: one G-lane subgroup per destination row
 // ------------------------------------------------------------------------------------------------
 template <int G, int MODE, int F4T>
-__global__ __launch_bounds__(kBlock) void agg_short_kernel(const AggLaunch L) {
-    const int gi = find_group(L);
-    const AggGroup &P = L.g[gi];
-    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / G) + (int)threadIdx.x / G;
+__device__ __forceinline__ void short_rows(const AggGroup &P, const int blk) {
+    const int item = blk * (kBlock / G) + (int)threadIdx.x / G;
     const int sl = (int)threadIdx.x % G;
     const bool valid = item < P.n_short;
     const int row = valid ? P.short_rows[item] : 0;
@@ -296,8 +294,19 @@ __device__ __forceinline__ void long_item(const AggGroup &P, const LongItem it, 
     if (sub == 0 && active) finish_row<MODE>(P, row, c4, it.end - it.beg, st, sum);
 }
 
+// One launch per (lane width, head class) of a level: workgroups [0, n_long_blocks) take the long rows and hub chunks
+// (one wave per item; heaviest work first), the workgroups after them the short rows (one G-lane subgroup per row), which
+// fill the machine while the last long items drain.  Round 2: two launches before (agg_long_* / agg_short_*); on a rank of
+// 8 the short-row launches were 12 us each for 2 us of work.
 template <int G, int MODE, int F4T>
-__global__ __launch_bounds__(kBlock) void agg_long_kernel(const AggLaunch L) {
+__global__ __launch_bounds__(kBlock) void agg_rows_kernel(const AggLaunch L) {
+    if ((int)blockIdx.x >= L.n_long_blocks) {
+        const int b = (int)blockIdx.x - L.n_long_blocks;
+        int gi = 0;
+        while (gi + 1 < L.n_groups && b >= L.blk_short[gi + 1]) ++gi;
+        short_rows<G, MODE, F4T>(L.g[gi], b - L.blk_short[gi]);
+        return;
+    }
     const int gi = find_group(L);
     const AggGroup &P = L.g[gi];
     const int wave = (int)threadIdx.x / kWave;
@@ -559,13 +568,37 @@ __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
     Soft st;
     st.init();
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = sub; c < count; c += NSG) {
-        const float *rec = P.partial + (size_t)(first + c) * rec_sz;
-        const float4 a = ld4(rec + c4);
-        if (MODE == AGG_GAT) {
-            st.merge(rec[P.W + kk], rec[P.W + kk + 1], a);
-        } else {
-            sum = add4(sum, a);
+    // a hub row of the 25m-shaped graph has ~300 chunk records: 8 of them are in flight per subgroup before the first
+    // merge (folded in the same chunk order as one at a time: the kernel was one dependent load per record, 30 us)
+    constexpr int UM = 8;
+    for (int c0 = sub; c0 < count; c0 += NSG * UM) {
+        float4 a[UM];
+        float m2[UM], s2[UM];
+#pragma unroll
+        for (int u = 0; u < UM; ++u) {
+            const int c = c0 + u * NSG;
+            const bool ok = c < count;
+            const float *rec = P.partial + (size_t)(first + (ok ? c : c0)) * rec_sz;
+            a[u] = ld4(rec + c4);
+            if (MODE == AGG_GAT) {
+                m2[u] = rec[P.W + kk];
+                s2[u] = rec[P.W + kk + 1];
+            }
+            // a slot past the end becomes the neutral record (weight 2^(kNegBig - m) = 0, state x 1): the merges below
+            // stay unconditional, so the compiler keeps the UM loads ahead of them instead of sinking each into its branch
+            if (!ok) {
+                a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                m2[u] = kNegBig;
+                s2[u] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UM; ++u) {
+            if (MODE == AGG_GAT) {
+                st.merge(m2[u], s2[u], a[u]);
+            } else {
+                sum = add4(sum, a[u]);
+            }
         }
     }
 #pragma unroll
@@ -597,13 +630,14 @@ __global__ __launch_bounds__(kBlock) void agg_merge_kernel(const AggLaunch L) {
 }
 
 
-// kernel names as rocprofv3 would group them: agg_{short,long,merge,longhot}_g<G>_{gat,gcn,mean}
+// profile names, as profiles/summarize.py derives them from rocprofv3's kernel names: agg_rows_g<G>_<mode> = the level
+// launch (long rows, hub chunks and short rows), agg_merge_* / agg_longhot_*
 template <int G, int MODE>
 const char *kname(int which) {
     static char names[4][32];
     static bool init = false;
     if (!init) {
-        const char *w[4] = {"short", "long", "merge", "longhot"};
+        const char *w[4] = {"short", "rows", "merge", "longhot"};
         const char *m = MODE == AGG_GAT ? "gat" : MODE == AGG_GCN ? "gcn" : MODE == AGG_WSUM ? "wsum" : "mean";
         for (int i = 0; i < 4; ++i) snprintf(names[i], sizeof(names[i]), "agg_%s_g%d_%s", w[i], G, m);
         init = true;
@@ -628,40 +662,33 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         pull_short += pull * g.msgs_short;
         table = table > g.table_rows * 4.0 * g.W ? table : g.table_rows * 4.0 * g.W;
     }
-    // short
+    // long rows + hub chunks first, short rows behind them, ONE launch (groups with an LDS image or already served by the
+    // fat-lane kernel keep their short rows here, their long items go elsewhere)
     L.n_groups = 0;
-    int blocks = 0;
-    for (int i = 0; i < n_sel; ++i) {
-        const AggGroup &g = base.g[sel[i]];
-        if (g.n_short <= 0) continue;
-        L.blk_start[L.n_groups] = blocks;
-        L.g[L.n_groups++] = g;
-        blocks += (g.n_short + (kBlock / G) - 1) / (kBlock / G);
-    }
-    L.blk_start[L.n_groups] = blocks;
-    if (blocks > 0) {
-        ProfScope ps(kname<G, MODE>(0), stream, bytes_short, pull_short, table);
-        hipLaunchKernelGGL((agg_short_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
-        PEA_HIP(hipGetLastError());
-    }
-    // long + hub chunks
-    L.n_groups = 0;
-    blocks = 0;
+    int blocks = 0, sblocks = 0;
     double pull_plain = 0.0, alg_plain = 0.0;
     for (int i = 0; i < n_sel; ++i) {
         const AggGroup &g = base.g[sel[i]];
-        if (g.n_long <= 0 || g.hot_col || g.skip_long) continue;
+        const bool long_here = g.n_long > 0 && !g.hot_col && !g.skip_long;
+        if (g.n_short <= 0 && !long_here) continue;
         L.blk_start[L.n_groups] = blocks;
-        L.g[L.n_groups++] = g;
+        L.blk_short[L.n_groups] = sblocks;
+        AggGroup &c = L.g[L.n_groups++];
+        c = g;
+        if (!long_here) c.n_long = 0;
+        if (g.n_short > 0) sblocks += (g.n_short + (kBlock / G) - 1) / (kBlock / G);
+        if (!long_here) continue;
         blocks += ((g.n_long + 3) / 4 + 7) / 8 * 8;  // groups start on a multiple of 8 workgroups (XCD round-robin)
         const double per_msg = 4.0 * g.W + 4.0 * g.idx_share + (MODE == AGG_GAT ? 4.0 * (g.W / g.F) : MODE == AGG_GCN ? 4.0 * g.idx_share : 0.0);
         alg_plain += per_msg * g.msgs_long;
         pull_plain += (4.0 * g.W + 4.0 + (MODE == AGG_GCN ? 4.0 : 0.0)) * g.msgs_long;
     }
     L.blk_start[L.n_groups] = blocks;
-    if (blocks > 0) {
-        ProfScope ps(kname<G, MODE>(1), stream, alg_plain, pull_plain, table);
-        hipLaunchKernelGGL((agg_long_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+    L.blk_short[L.n_groups] = sblocks;
+    L.n_long_blocks = blocks;
+    if (blocks + sblocks > 0) {
+        ProfScope ps(kname<G, MODE>(1), stream, alg_plain + bytes_short, pull_plain + pull_short, table);
+        hipLaunchKernelGGL((agg_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
     // groups with an LDS image of their hottest sources: one persistent launch each

@@ -11,6 +11,9 @@ constexpr float kNegBig = -3.0e38f;  // finite "minus infinity" for the running 
 struct AggLaunch {
     int n_groups;
     int blk_start[kMaxAggGroups + 1];
+    // agg_rows_kernel: workgroups [0, n_long_blocks) walk blk_start (long items), the rest blk_short (short rows)
+    int n_long_blocks;
+    int blk_short[kMaxAggGroups + 1];
     AggGroup g[kMaxAggGroups];
 };
 

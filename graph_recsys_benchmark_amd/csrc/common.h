@@ -308,6 +308,7 @@ constexpr int kMaxMlp2Chan = 32;   // the launch descriptor travels as a kernel 
 struct Mlp2Chan {
     const float *w0, *b0, *w1;            // first-layer weight / bias, second-layer weight (raw parameter tensors)
     const float *att_src0, *att_dst0;     // GAT first layer: att_j, att_i [hid]
+    const float *b1, *att_src1, *att_dst1;  // second layer: bias (may be null), GAT att_j / att_i [out]
     float *ws, *wd;                       // GAT: out: att vectors in x space, (W^T att) * log2(e)  [emb]
     const unsigned char *deg0;            // [N] 1 = no incoming edge under the channel's first relation
     const float *dinv;                    // GCN: deg^-1/2 of the first relation (node-indexed), else null
@@ -323,6 +324,9 @@ struct Mlp2Launch {
     const float *a0;                      // [N, ld_a0]
     float *t1;                            // [N, ld_t1]
     float *images;                        // [n][mlp2_image_bytes] packed weights (written by launch_mlp2_pack)
+    // the second layer's aggregation reads its bias / attention rows from the level's packed rows (column t1_col of the
+    // channel); the same pack launch writes them, so the schedule needs no other weight packing
+    float *bias1, *att_src1, *att_dst1;
     int64_t ldx, ld_a0, ld_t1;
     Mlp2Chan c[kMaxMlp2Chan];
 };

@@ -54,6 +54,13 @@ __global__ __launch_bounds__(256) void mlp2_pack_kernel(const Mlp2Launch L) {
         const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * half;
         b0p[idx] = C.b0 ? C.b0[i] : 0.f;
     }
+    for (int o = threadIdx.x; o < OUT; o += 256) {
+        L.bias1[C.t1_col + o] = C.b1 ? C.b1[o] : 0.f;
+        if (gat) {
+            L.att_src1[C.t1_col + o] = C.att_src1[o] * kLog2e;   // att_j multiplies the SOURCE row
+            L.att_dst1[C.t1_col + o] = C.att_dst1[o] * kLog2e;   // att_i multiplies the TARGET row
+        }
+    }
     if (gat) {
         // logits of the first layer from x itself: (W x) . att = x . (W^T att); log2(e) folded in like the level-wise pack
         for (int k = threadIdx.x; k < EMB; k += 256) {

@@ -796,6 +796,9 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         ML.t1 = wsf + L1.off_t;
         ML.ld_t1 = L1.ld_t;
         ML.images = pack + m->mlp2_img_off;
+        ML.bias1 = pack + L1.bias_off;
+        ML.att_src1 = kind == PEA_KIND_GAT ? pack + L1.att_src_off : nullptr;
+        ML.att_dst1 = kind == PEA_KIND_GAT ? pack + L1.att_dst_off : nullptr;
         const bool fc = d.gcn_deg_from_col != 0;
         std::vector<AggGroup> gs;
         size_t part_off = 0;
@@ -819,9 +822,14 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 C.att_dst0 = param(u, 1);   // att_i multiplies the TARGET row
                 C.att_src0 = param(u, 2);   // att_j multiplies the SOURCE row
                 C.b0 = param(u, 3);
-                PEA_REQUIRE(C.att_src0 && C.att_dst0, PEA_ERR_ARG, "forward: null att_i/att_j (channel %d)", u.p);
+                C.att_dst1 = param(*u1, 1);
+                C.att_src1 = param(*u1, 2);
+                C.b1 = param(*u1, 3);
+                PEA_REQUIRE(C.att_src0 && C.att_dst0 && C.att_src1 && C.att_dst1, PEA_ERR_ARG,
+                            "forward: null att_i/att_j (channel %d)", u.p);
             } else {
                 C.b0 = param(u, 1);
+                C.b1 = param(*u1, 1);
                 PEA_TRY(ensure_dinv(plan, u.rel, fc, stream));
                 C.dinv = fc ? R.dinv_col : R.dinv_row;
             }
@@ -872,7 +880,8 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
     const int s_beg = stage < 0 ? 0 : stage, s_end = stage < 0 ? n_levels : stage + 1;
     PEA_REQUIRE(s_beg >= 0 && s_end <= n_levels, PEA_ERR_ARG, "forward: stage %d of %d", stage, n_levels);
     for (int k = s_beg; k < s_end; ++k) {
-        if (k == 0) PEA_TRY(pack_weights());
+        // the two-step schedule packs everything it reads in its own launch (launch_mlp2_pack)
+        if (k == 0 && !(m->fused2 && !training)) PEA_TRY(pack_weights());
         if (m->fused2 && !training) {
             if (k == 0) PEA_TRY(run_fused2_stage0());
             else PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
