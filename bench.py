@@ -259,12 +259,15 @@ def kernel_roofline(name, rec, traffic_tab, flops):
     return out
 
 
-def transform_flops(sp, n, steps):
-    """Useful flops of the dense transforms of a 2-step GAT / GCN model over `steps` steps, by kernel name: the level-wise
+def transform_flops(sp, n, steps, kind='gat'):
+    """Useful flops of the dense transforms of a 2-step model over `steps` steps, by kernel name: the level-wise
     schedule's two launches (PEA_FUSED2=0) or the two-step schedule's one (csrc/mlp2.hip: both layers chained; the
-    padding of the second product to 32 output rows is not counted)."""
+    padding of the second product to 32 output rows is not counted).  SAGE: every layer is lin_rel + lin_root (twice the
+    products), all of them inside the one launch of the two-step schedule."""
     l0 = 2.0 * n * sp['emb_dim'] * sp['hidden_size'] * sp['num_metapaths'] * steps
     l1 = 2.0 * n * sp['hidden_size'] * sp['repr_dim'] * sp['num_metapaths'] * steps
+    if kind == 'sage':
+        return {'mlp2_fused': 2.0 * (l0 + l1)}
     return {'gemm_mfma_shared': l0, 'gemm_mfma_narrow': l1, 'mlp2_fused': l0 + l1}
 
 
@@ -410,9 +413,9 @@ def main():
     if prof:
         traffic_tab = load_traffic(args.preset, args.kind, args.scale, max(world, args.emulate_world or 1))
         flops = {}
-        if args.kind in ('gat', 'gcn') and single_gpu_schedule(world, args):     # the two transform launches of a 2-step model
+        if single_gpu_schedule(world, args):     # the transform launch(es) of a 2-step model
             sp, n = dataset.spec, dataset.num_nodes
-            flops = transform_flops(sp, n, args.steps)
+            flops = transform_flops(sp, n, args.steps, args.kind)
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         out['roofline'] = kernel_roofline(dom[0], dom[1], traffic_tab, flops)
         gathers = {k: v for k, v in prof.items() if v[3] > 0}

@@ -309,6 +309,8 @@ struct Mlp2Chan {
     const float *w0, *b0, *w1;            // first-layer weight / bias, second-layer weight (raw parameter tensors)
     const float *att_src0, *att_dst0;     // GAT first layer: att_j, att_i [hid]
     const float *b1, *att_src1, *att_dst1;  // second layer: bias (may be null), GAT att_j / att_i [out]
+    const float *w0_root, *w1_root;       // SAGE: lin_root.weight of the two layers (w0 / w1 are lin_rel.weight, b0 / b1 its bias)
+    int r1_col;                           // SAGE: column of the channel's root term in r1
     float *ws, *wd;                       // GAT: out: att vectors in x space, (W^T att) * log2(e)  [emb]
     const unsigned char *deg0;            // [N] 1 = no incoming edge under the channel's first relation
     const float *dinv;                    // GCN: deg^-1/2 of the first relation (node-indexed), else null
@@ -327,11 +329,16 @@ struct Mlp2Launch {
     // the second layer's aggregation reads its bias / attention rows from the level's packed rows (column t1_col of the
     // channel); the same pack launch writes them, so the schedule needs no other weight packing
     float *bias1, *att_src1, *att_dst1;
+    // SAGE: in_c(n) = [mean_j x_j | x_n] (the mean block a0_col is shared by the channels of one first relation, zero for
+    // rows without incoming edges), and the second product gives T_1 = H lin_rel^T (the gather source of layer 2) AND the
+    // root term H lin_root^T + bias, written to r1 where the layer-2 aggregation adds the neighbour mean
+    float *r1;
+    int64_t ld_r1;
     int64_t ldx, ld_a0, ld_t1;
     Mlp2Chan c[kMaxMlp2Chan];
 };
-size_t mlp2_image_bytes(int emb, int hid);
-bool mlp2_supported(int emb, int hid, int out);
+size_t mlp2_image_bytes(int kind, int emb, int hid);
+bool mlp2_supported(int kind, int emb, int hid, int out);
 int launch_mlp2_pack(const Mlp2Launch &L, hipStream_t stream);
 int launch_mlp2(const Mlp2Launch &L, const int *rows, int64_t n_rows, hipStream_t stream);
 

@@ -65,9 +65,11 @@ int build_schedule(pea_model *m) {
         bool all2 = true;
         for (int p = 0; p < P; ++p) all2 = all2 && m->steps[(size_t)p] == 2;
         const char *env = getenv("PEA_FUSED2");
-        m->fused2 = all2 && !m->backward && !m->single_conv && (d.kind == PEA_KIND_GAT || d.kind == PEA_KIND_GCN) &&
-                    d.heads == 1 && P <= kMaxMlp2Chan && mlp2_supported(d.emb_dim, d.hidden_size, d.repr_dim) &&
-                    (plan->flags & PEA_PLAN_SELF_LOOPS) && !(env && atoi(env) == 0);
+        // GAT / GCN: plans with self loops (a row without incoming edges aggregates to itself: mlp2 reads x for it);
+        // SAGE: no self loops by definition, such a row's mean is 0
+        const bool loops_ok = d.kind == PEA_KIND_SAGE ? !(plan->flags & PEA_PLAN_SELF_LOOPS) : (plan->flags & PEA_PLAN_SELF_LOOPS) != 0;
+        m->fused2 = all2 && !m->backward && !m->single_conv && (d.heads == 1 || d.kind != PEA_KIND_GAT) && P <= kMaxMlp2Chan &&
+                    mlp2_supported(d.kind, d.emb_dim, d.hidden_size, d.repr_dim) && loops_ok && !(env && atoi(env) == 0);
         m->ld_a0 = pad_ld(P * d.emb_dim);
     }
     m->levels.assign((size_t)Smax, Level());
@@ -282,7 +284,10 @@ int build_schedule(pea_model *m) {
             if (m->fused2 && s == 0) {
                 // two-step schedule: no T_0 / O_0; per channel its index arrays and the aggregates A_0 of the rows that
                 // have incoming edges (written once, read once)
-                for (const Unit &u : L.units) {
+                int prev_rel = -1;
+                for (const Unit &u : L.units) {   // (SAGE: one mean per distinct relation, shared by its channels)
+                    if (d.kind == PEA_KIND_SAGE && u.rel == prev_rel) continue;
+                    prev_rel = u.rel;
                     const Relation &R = plan->rels[(size_t)u.rel];
                     const double rows_with_edges = (double)(R.n_short - R.n_short0) + R.n_direct + R.n_hub;
                     m->compulsory_bytes += 4.0 * (double)R.e_kept + 4.0 * (Nr + 1.0) + 8.0 * rows_with_edges * d.emb_dim;
@@ -310,7 +315,7 @@ int build_schedule(pea_model *m) {
     }
     if (m->fused2) {
         m->mlp2_img_off = pack;
-        pack = pad_off(pack + (size_t)P * (mlp2_image_bytes(d.emb_dim, d.hidden_size) / sizeof(float)));
+        pack = pad_off(pack + (size_t)P * (mlp2_image_bytes(d.kind, d.emb_dim, d.hidden_size) / sizeof(float)));
         m->mlp2_att_off = pack;
         pack = pad_off(pack + (size_t)2 * P * (size_t)d.emb_dim);
     }
@@ -802,6 +807,67 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         const bool fc = d.gcn_deg_from_col != 0;
         std::vector<AggGroup> gs;
         size_t part_off = 0;
+        if (kind == PEA_KIND_SAGE) {
+            // one mean of x rows per distinct first relation (units are sorted by relation), shared by its channels; rows
+            // without incoming edges are not visited (their mean is 0: mlp2 feeds zeros)
+            ML.r1 = X;
+            ML.ld_r1 = ldX;
+            int n_rel = 0, prev_rel = -1;
+            for (size_t ui = 0; ui < L0.units.size(); ++ui) {
+                const Unit &u = L0.units[ui];
+                const Unit *u1 = nullptr;
+                for (const Unit &c : L1.units)
+                    if (c.p == u.p) u1 = &c;
+                PEA_REQUIRE(u1 != nullptr, PEA_ERR_ARG, "fused schedule: channel %d has no second layer", u.p);
+                Relation &R = plan->rels[(size_t)u.rel];
+                if (u.rel != prev_rel) {
+                    prev_rel = u.rel;
+                    AggGroup a{};
+                    a.rowptr = R.rowptr;
+                    a.col = R.col;
+                    a.short_rows = R.short_rows + R.n_short0;
+                    a.n_short = R.n_short - R.n_short0;
+                    a.long_items = R.long_items;
+                    a.n_long = R.n_long;
+                    a.hub_rows = R.hub_rows;
+                    a.hub_first = R.hub_first;
+                    a.hub_count = R.hub_count;
+                    a.n_hub = R.n_hub;
+                    a.W = d.emb_dim;
+                    a.F = d.emb_dim;
+                    a.feat = x;
+                    a.ld_feat = (int)ldx;
+                    a.feat_self = x;
+                    a.ld_self = (int)ldx;
+                    a.out = A0 + (size_t)n_rel * d.emb_dim;
+                    a.ld_out = m->ld_a0;
+                    a.partial = partial + part_off;
+                    part_off += (size_t)slots_of(m, u.rel) * partial_record_floats(d.emb_dim, d.emb_dim);
+                    a.msgs_short = (double)R.edges_short;
+                    a.msgs_long = (double)R.edges_long;
+                    a.idx_share = 1.0;
+                    a.table_rows = (double)R.src_span;
+                    gs.push_back(a);
+                    ++n_rel;
+                }
+                Mlp2Chan &C = ML.c[ui];
+                C.w0 = param(u, 0);          // lin_rel.weight
+                C.b0 = param(u, 1);          // lin_rel.bias
+                C.w0_root = param(u, 2);     // lin_root.weight
+                C.w1 = param(*u1, 0);
+                C.b1 = param(*u1, 1);
+                C.w1_root = param(*u1, 2);
+                PEA_REQUIRE(C.w0 && C.w1 && C.w0_root && C.w1_root, PEA_ERR_ARG, "forward: null weight pointer (channel %d)", u.p);
+                C.a0_col = (n_rel - 1) * d.emb_dim;
+                C.t1_col = u1->t_col;
+                C.r1_col = u1->o_col;
+                C.deg0 = R.deg0;
+            }
+            PEA_TRY(launch_mlp2_pack(ML, stream));
+            for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+                PEA_TRY(launch_aggregate(AGG_MEAN, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+            return launch_mlp2(ML, own_rows, n_own, stream);
+        }
         for (size_t ui = 0; ui < L0.units.size(); ++ui) {
             const Unit &u = L0.units[ui];
             const Unit *u1 = nullptr;
@@ -884,7 +950,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         if (k == 0 && !(m->fused2 && !training)) PEA_TRY(pack_weights());
         if (m->fused2 && !training) {
             if (k == 0) PEA_TRY(run_fused2_stage0());
-            else PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN));
+            else PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : kind == PEA_KIND_GCN ? AGG_GCN : AGG_MEAN));
         } else if (kind == PEA_KIND_SAGE && !m->sage2) {
             PEA_TRY(run_groups(k, AGG_MEAN));
             PEA_TRY(run_gemm(k));
