@@ -29,10 +29,10 @@ constexpr float kLog2e = 1.44269504088896340736f;
 // image of one channel, in floats: [Wt0: HT * ET * 64 * 4][Wt1: HT * 4 * 64 * 4][b0p: 2 * HT * 16]
 __host__ __device__ inline int mlp2_image_floats(int ET, int HT) { return HT * ET * 256 + HT * 1024 + 2 * HT * 16; }
 
-// kPackSplit blocks per channel (the launch is pure latency: a few thousand elements each): the LDS images of its two
+// gridDim.x / n blocks per channel (the launch is pure latency: 2048 image elements per block): the LDS images of its two
 // weight matrices + (GAT) the attention vectors in x space + the second layer's bias / attention rows
-constexpr int kPackSplit = 4;
 __global__ __launch_bounds__(256) void mlp2_pack_kernel(const Mlp2Launch L) {
+    const int kPackSplit = (int)gridDim.x / L.n;
     const int chan = (int)blockIdx.x / kPackSplit, part = (int)blockIdx.x % kPackSplit;
     const Mlp2Chan &C = L.c[chan];
     const int EMB = L.emb, HID = L.hid, OUT = L.out;
@@ -359,7 +359,9 @@ bool mlp2_supported(int kind, int emb, int hid, int out) {
 
 int launch_mlp2_pack(const Mlp2Launch &L, hipStream_t stream) {
     ProfScope ps("pack_weights2", stream);
-    hipLaunchKernelGGL(mlp2_pack_kernel, dim3((unsigned)L.n * kPackSplit), dim3(256), 0, stream, L);
+    const int kt = (L.kind == PEA_KIND_SAGE ? 2 : 1) * L.emb / 8, ht = L.hid / 32;
+    const int split = std::max(4, std::min(32, mlp2_image_floats(kt, ht) / 2048));
+    hipLaunchKernelGGL(mlp2_pack_kernel, dim3((unsigned)(L.n * split)), dim3(256), 0, stream, L);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
