@@ -99,6 +99,9 @@ SIGNATURES = {
                                    C.POINTER(C.c_double), C.POINTER(_int)]),
     'pea_entity_reg_workspace_bytes': (C.c_size_t, [_i64, _int]),
     'pea_entity_reg': (_int, [_i64, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, C.c_size_t, _vp]),
+    'pea_bpr_train_workspace_bytes': (C.c_size_t, [_i64]),
+    'pea_bpr_train_supported': (_int, [_int, _int]),
+    'pea_bpr_train': (_int, [_i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     'pea_rows_pack': (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp, _i64, _vp]),
     'pea_rows_unpack': (_int, [_vp, _i64, _vp, _int, _vp, _i64, _vp, _i64, _int, _vp]),
     'pea_rows_select_owned': (_int, [_vp, _i64, _int, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),

@@ -492,3 +492,56 @@ def rank_eval(repr_, unids, cand, fc1_w, fc1_b, fc2_w, fc2_b):
         raise IndexError(_lib.last_error())
     _lib.check(rc)
     return scores, rank, auc, loss
+
+
+class _BprTrainLoss(torch.autograd.Function):
+    """loss = -sum_b log sigmoid(score(u_b, i+_b) - score(u_b, i-_b)) over the fused rows of the batch's stack rows, and its
+    whole backward, in one HIP launch (csrc/bpr_train.hip) + two fixed-order reductions for the parameter gradients
+    (pea_grad_weight).  Reference: models/base.py:193-203 (fusion), :208-214 (fc1 / fc2 scorer), :46-48 (BPR loss) under
+    loss.backward() (solvers.py:213-214)."""
+
+    @staticmethod
+    def forward(ctx, picked, att, fc1_w, fc1_b, fc2_w, fc2_b):
+        lib = _lib.require_device()
+        n3, p_, r_ = picked.shape
+        b = n3 // 3
+        rows = picked.detach()
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        dev = rows.device
+        keep = [t.detach().contiguous() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
+        att_c = att.detach().contiguous().view(-1) if att is not None else None
+        grad_rows = torch.empty((n3, p_ * r_), dtype=torch.float32, device=dev)
+        dhx = torch.empty((2 * b, r_ + 4), dtype=torch.float32, device=dev)
+        zx = torch.empty((2 * b, 3 * r_ + 4), dtype=torch.float32, device=dev)
+        p4 = (p_ + 3) // 4 * 4
+        dsc = torch.empty((n3, p4), dtype=torch.float32, device=dev) if att is not None else None
+        ws_bytes = int(lib.pea_bpr_train_workspace_bytes(b))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(lib.pea_bpr_train(b, p_, r_, _lib.ptr(rows), p_ * r_, _lib.ptr(att_c), _lib.ptr(keep[0]), _lib.ptr(keep[1]),
+                                     _lib.ptr(keep[2]), _lib.ptr(keep[3]), _lib.ptr(loss), _lib.ptr(grad_rows), _lib.ptr(dhx),
+                                     _lib.ptr(zx), _lib.ptr(dsc), _lib.ptr(ws), ws_bytes, _lib.current_stream()))
+        g = grad_weight([(dhx, zx)])[0]                    # [R + 4, 3R + 4]
+        d_att = None
+        if att is not None:
+            full = grad_weight([(dsc, rows.view(n3, p_ * r_))])[0]      # [P4, P * R]: the diagonal R-blocks are d att[p]
+            d_att = torch.stack([full[q, q * r_:(q + 1) * r_] for q in range(p_)]).view(att.shape)
+        ctx.grads = (grad_rows.view(n3, p_, r_), d_att, g[:r_, :2 * r_], g[:r_, 3 * r_], g[r_, 2 * r_:3 * r_].view(fc2_w.shape),
+                     g[r_, 3 * r_].view(fc2_b.shape))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(None if t is None else t * g for t in ctx.grads)
+
+
+def bpr_train_supported(num_channels, repr_dim):
+    return bool(_lib.require_device().pea_bpr_train_supported(int(num_channels), int(repr_dim)))
+
+
+def bpr_train_loss(picked, att, fc1_w, fc1_b, fc2_w, fc2_b):
+    """Differentiable BPR loss of a batch from its stack rows picked [3B, P, R] (rows 3b, 3b+1, 3b+2 = user, positive,
+    negative of triple b): channel fusion ('att' with the [.., P, R] attention tensor, 'mean' with att=None), the fc1 / fc2
+    scorer and the loss, forward and backward in HIP."""
+    return _BprTrainLoss.apply(picked, att, fc1_w, fc1_b, fc2_w, fc2_b)

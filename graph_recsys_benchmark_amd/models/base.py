@@ -244,7 +244,11 @@ class PEABaseRecsysModel(GraphRecsysModel):
             picked = _ShardedRows.apply(stack.view(stack.shape[0], -1), ids, eng.plan.layout).view(-1, eng.P, eng.repr_dim)
         else:
             picked = stack[ids]
-        rows = self._fuse_torch(picked).view(b, 3, -1)
+        if _engine.bpr_train_supported(eng.P, eng.repr_dim):
+            # fusion + scorer + loss of the batch's rows, forward and backward, in one HIP launch (csrc/bpr_train.hip)
+            return _engine.bpr_train_loss(picked, self.att if self.channel_aggr == 'att' else None, self.fc1.weight,
+                                          self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        rows = self._fuse_torch(picked).view(b, 3, -1)   # repr_dim > 32: the same head in torch ops on the GPU
 
         def score(i):
             return self.fc2(torch.relu(self.fc1(torch.cat([rows[:, 0], rows[:, i]], dim=-1))))

@@ -35,6 +35,7 @@
  *   pea_weighted_aggregate   nn/kgat_conv.py:36-44, nn/kgcn_conv.py:32-37, nn/ngcf_conv.py:42-45 (message + scatter)
  *   pea_sample_negatives     datasets/movielens.py:920-940 (an on-GPU sampler NEXT TO the bit-exact host mirror)
  *   pea_entity_reg           models/base.py:50-73 (entity-aware regulariser of the loss, value + gradient rows)
+ *   pea_bpr_train            models/base.py:193-214 + 46-48 under autograd (fusion + scorer + BPR loss, forward + backward)
  *   pea_model_forward_stage[_train], pea_model_backward_level (phases), pea_rows_pack / _unpack / _select_owned,
  *   pea_grad_weight_sharded, pea_dense_batch_rows
  *                       no counterpart in the reference (its step is single-process): one rank's share of a step
@@ -332,6 +333,23 @@ size_t pea_entity_reg_workspace_bytes(int64_t B, int emb_dim);
 int pea_entity_reg(int64_t B, int emb_dim, int64_t num_nodes, const float *x, int64_t ldx, const int64_t *batch,
                    int64_t batch_stride, float *out_reg, float *grad_rows, void *workspace, size_t workspace_bytes,
                    void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-step head (solvers.py:213-214, loss = model.loss(batch); loss.backward()): channel fusion
+ * (models/base.py:193-203), the fc1 / fc2 scorer (:208-214) and the BPR loss (:46-48) of the B triples of a batch,
+ * forward and backward in one launch.  rows [3B, ld_rows]: the P*R stack row of (user, pos item, neg item) of triple b at
+ * rows 3b, 3b+1, 3b+2.  att: [P*R] ('att' fusion) or NULL ('mean').  Outputs: *out_loss; grad_rows [3B, P*R] = d loss /
+ * d rows; and the operands of the parameter gradients, which the caller reduces with pea_grad_weight (fixed order):
+ *   dhx [2B, R+4], zx [2B, 3R+4]:  G = dhx^T zx  ->  d fc1.weight = G[0:R, 0:2R], d fc1.bias = G[0:R, 3R],
+ *                                                     d fc2.weight = G[R, 2R:3R],  d fc2.bias = G[R, 3R]
+ *   dsc [3B, P4] (P4 = P rounded up to 4; 'att' only):  d att[p, :] = (dsc^T rows)[p, p*R:(p+1)*R]
+ * repr_dim R: a multiple of 4, <= 32 (pea_bpr_train_supported).  No atomics, fixed reduction order.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pea_bpr_train_workspace_bytes(int64_t B);
+int pea_bpr_train_supported(int P, int R);
+int pea_bpr_train(int64_t B, int P, int R, const float *rows, int64_t ld_rows, const float *att, const float *fc1_w,
+                  const float *fc1_b, const float *fc2_w, const float *fc2_b, float *out_loss, float *grad_rows,
+                  float *dhx, float *zx, float *dsc, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange helpers (one process per GPU; the collectives themselves are RCCL calls made by the host

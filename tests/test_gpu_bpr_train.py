@@ -1,0 +1,95 @@
+"""Training-step head in HIP (csrc/bpr_train.hip: channel fusion + fc1/fc2 scorer + BPR loss, forward and backward in one
+launch) against float64 torch autograd of the reference's formulas (models/base.py:193-203, :208-214, :46-48)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(picked, att, fc1_w, fc1_b, fc2_w, fc2_b):
+    x = picked
+    if att is None:
+        fused = x.mean(dim=1)
+    else:
+        a = torch.softmax(torch.sum(x * att, dim=-1), dim=-1).unsqueeze(-1)
+        fused = torch.sum(x * a, dim=1)
+    rows = fused.view(-1, 3, fused.shape[-1])
+
+    def score(i):
+        z = torch.cat([rows[:, 0], rows[:, i]], dim=-1)
+        return torch.relu(z @ fc1_w.t() + fc1_b) @ fc2_w.t() + fc2_b
+
+    return -(score(1) - score(2)).sigmoid().log().sum()
+
+
+@pytest.mark.parametrize('b,p,r,mode', [(257, 9, 16, 'att'), (64, 5, 8, 'mean'), (130, 3, 12, 'att'), (33, 13, 32, 'att'),
+                                        (1, 9, 16, 'att'), (100, 1, 4, 'att')])
+def test_bpr_train_matches_float64_autograd(b, p, r, mode):
+    from graph_recsys_benchmark_amd import engine
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(1000 * b + 10 * p + r)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s)
+    tensors = dict(picked=mk(3 * b, p, r, s=0.7), att=mk(1, p, r, s=0.5) if mode == 'att' else None, fc1_w=mk(r, 2 * r, s=0.4),
+                   fc1_b=mk(r, s=0.1), fc2_w=mk(1, r, s=0.5), fc2_b=mk(1, s=0.1))
+    ref_in = {k: (v.double().requires_grad_(True) if v is not None else None) for k, v in tensors.items()}
+    ref = _reference(**ref_in)
+    ref.backward()
+    hip_in = {k: (v.to(dev).requires_grad_(True) if v is not None else None) for k, v in tensors.items()}
+    assert engine.bpr_train_supported(p, r)
+    loss = engine.bpr_train_loss(hip_in['picked'], hip_in['att'], hip_in['fc1_w'], hip_in['fc1_b'], hip_in['fc2_w'],
+                                 hip_in['fc2_b'])
+    (2.0 * loss).backward()      # a non-unit upstream gradient must scale every gradient
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-6 * b
+    for k, v in hip_in.items():
+        if v is None:
+            continue
+        want = 2.0 * ref_in[k].grad
+        got = v.grad.double().cpu()
+        assert got.shape == want.shape, k
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * float(want.abs().max()) + 1e-7, (k, err, float(want.abs().max()))
+
+
+@pytest.mark.parametrize('aggr', ['att', 'mean'])
+def test_training_loss_of_a_model_uses_the_hip_head_and_matches_the_torch_head(aggr):
+    """model.loss(batch) under autograd: the HIP head against the torch-op head it replaced (same stack rows); the
+    float64 check of the whole step is tests/test_gpu_backward.py."""
+    import numpy as np
+    from graph_recsys_benchmark_amd import engine
+    from tests.helpers import build_model, random_hin, random_state_dict
+    n, blocks, rel = random_hin(47, n_user=900, n_item=300, n_attr=20, e_u2i=9000, e_attr=800)
+    u2i, a2i = rel['u2i'], rel['a2i']
+    flip = lambda e: np.ascontiguousarray(e[::-1])
+    edges = [[u2i, flip(u2i)], [flip(u2i), u2i], [a2i, flip(u2i)]]
+    model = build_model('gat', n, edges, [2, 2, 2], 32, 32, 16, channel_aggr=aggr)
+    model.load_state_dict(random_state_dict(model, 9, scale=0.25))
+    rng = np.random.default_rng(3)
+    batch = torch.from_numpy(np.stack([rng.integers(*blocks['u'], size=200), rng.integers(*blocks['i'], size=200),
+                                       rng.integers(*blocks['i'], size=200)], axis=1).astype(np.int64)).cuda()
+    model.train()
+    calls = []
+    orig_loss = engine.bpr_train_loss
+    engine.bpr_train_loss = lambda *a: (calls.append(1), orig_loss(*a))[1]
+    try:
+        model.zero_grad()
+        loss = model.loss(batch)
+        loss.backward()
+    finally:
+        engine.bpr_train_loss = orig_loss
+    assert calls, 'the training loss did not go through csrc/bpr_train.hip'
+    got = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    orig = engine.bpr_train_supported
+    engine.bpr_train_supported = lambda *_: False     # the torch-op head (kept for repr_dim > 32)
+    try:
+        model.zero_grad()
+        loss2 = model.loss(batch)
+        loss2.backward()
+    finally:
+        engine.bpr_train_supported = orig
+    assert abs(float(loss) - float(loss2)) <= 1e-5 * abs(float(loss2))
+    for k, v in model.named_parameters():
+        assert (v.grad is None) == (k not in got), k
+        if v.grad is None:
+            continue
+        scale = float(v.grad.abs().max())
+        assert float((got[k] - v.grad).abs().max()) <= 2e-4 * scale + 1e-7, k
