@@ -61,8 +61,10 @@ class _Slice:
         self.off, self.n, self.shape = off, n, shape
 
 
-def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
-    """Gradients of sum(stack * d_stack) wrt x and every conv parameter.  Returns (dx, [tuple per layer])."""
+def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compact=None):
+    """Gradients of sum(stack * d_stack) wrt x and every conv parameter.  Returns (dx, [tuple per layer]).
+    compact = (ids, rows): d_stack given as the gradient rows [len(ids), P * R] of the stack rows `ids` (int64; duplicates
+    are summed in position order, ids < 0 skipped) instead of a dense [N, P, R] tensor (PEALossFunction)."""
     lib = _lib.load()
     if not engine.enable_backward:
         raise RuntimeError('engine was built without enable_backward')
@@ -91,7 +93,17 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None):
     gpack = wsf[lay.off_gpack:lay.off_gpack + lay.pack_floats]
     # 1. gradient of the last-layer outputs, internal column order
     dX = _view(wsf, lay.off_dx, n, lay.ld_x)
-    if active_ids is not None:
+    if compact is not None:
+        # the batch's gradient rows go straight into the internal column order, duplicates summed in a fixed order, one launch
+        from .engine import rows_scatter_sum
+        col_of = [0] * engine.P
+        for lv in lay.levels:
+            for u in lv['units']:
+                if u['last']:
+                    col_of[u['p']] = u['o_col']
+        dX.zero_()
+        rows_scatter_sum(compact[0], compact[1], engine.P, engine.repr_dim, col_of, dX)
+    elif active_ids is not None:
         # d_stack is zero outside the rows the loss read: clear once, then move those rows only
         dX.zero_()
         rows = d_stack[active_ids]                                              # [B', P, R]
@@ -324,3 +336,69 @@ class PEAStackFunction(torch.autograd.Function):
             for t, gt in zip(lp, g):
                 out.append(None if t is None else gt.reshape(t.shape))
         return (None, dx, None, None, *out)
+
+
+class PEALossFunction(torch.autograd.Function):
+    """The whole training-step loss of a PEA model as ONE autograd node: conv stack forward (HIP), the batch's stack rows,
+    fusion + scorer + BPR loss with their backward (csrc/bpr_train.hip), and in backward() the batch's gradient rows
+    scattered straight into the output-gradient buffer (pea_rows_scatter_sum) before the conv stack's HIP backward.
+    Compared with PEAStackFunction + torch ops on top, autograd never builds the dense [N, P, R] gradient of the stack
+    (two 158 MB fills, a sort-based index backward and nine index_puts per step on the 25m-shaped graph).
+    Reference: solvers.py:213-214 (loss = model.loss(batch); loss.backward())."""
+
+    @staticmethod
+    def forward(ctx, engine, x, n_slots, options, ids, att, fc1_w, fc1_b, fc2_w, fc2_b, *flat):
+        from .engine import bpr_train_raw
+        layer_params = [tuple(flat[i:i + n_slots]) for i in range(0, len(flat), n_slots)]
+        options = options or StackOptions()
+        fuse_att = options.fuse_att
+        if fuse_att is None:
+            fuse_att = torch.zeros(engine.P, engine.repr_dim, device=x.device)
+        options.fused, stack = engine.forward(layer_params, x, att=fuse_att, masked=options.fuse_masked, want_stack=True,
+                                              train=True, gather=False)
+        table = stack.view(stack.shape[0], -1)
+        if engine.sharded:
+            # every rank holds the stack rows it owns: the batch's rows are summed from their owners (one all-reduce of
+            # [3B, P * R], exact: x + 0); the head is computed replicated; only owned rows receive a gradient here
+            layout = engine.plan.layout
+            picked = layout.gather_rows(table, ids)
+            ids_b = torch.where(layout.owner(ids) == layout.rank, ids, torch.full_like(ids, -1))
+        else:
+            picked, ids_b = table[ids], ids
+        loss, grad_rows, head = bpr_train_raw(picked.view(-1, engine.P, engine.repr_dim), att, fc1_w, fc1_b, fc2_w, fc2_b)
+        ctx.engine, ctx.n_slots, ctx.ids, ctx.ids_b = engine, n_slots, ids, ids_b
+        ctx.grad_rows, ctx.head = grad_rows, head
+        ctx.active_rows = None
+        if engine.kind == 'gat':
+            ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
+            ctx.active_rows[ids] = 1
+        ctx.save_for_backward(x, *[t for t in flat if t is not None])
+        ctx.present = [t is not None for t in flat]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = list(ctx.saved_tensors)
+        x, rest = saved[0], saved[1:]
+        flat, it = [], iter(rest)
+        for p in ctx.present:
+            flat.append(next(it) if p else None)
+        n_slots = ctx.n_slots
+        layer_params = [tuple(flat[i:i + n_slots]) for i in range(0, len(flat), n_slots)]
+        lib = _lib.load()
+        mask = ctx.active_rows
+        with torch.no_grad():
+            if mask is not None:
+                _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, _lib.ptr(mask)))
+            try:
+                dx, grads = backward_conv_stack(ctx.engine, None, x, layer_params, ctx.ids, compact=(ctx.ids_b, ctx.grad_rows))
+            finally:
+                if mask is not None:
+                    _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, None))
+            # everything above is linear in the upstream gradient: scale once at the end
+            out = []
+            for lp, gl in zip(layer_params, grads):
+                for t, gt in zip(lp, gl):
+                    out.append(None if t is None else gt.reshape(t.shape) * g)
+            head = tuple(None if t is None else t * g for t in ctx.head)
+            return (None, dx * g, None, None, None) + head + tuple(out)

@@ -12,6 +12,8 @@
 // (solvers.py:213-214 loss.backward()); here one thread owns a triple: its three rows stay in registers between the
 // forward and the backward, the fc weights and the attention vectors sit in LDS.  No atomics: the loss is summed per
 // block in thread order and the blocks in index order.
+#include <algorithm>
+
 #include "common.h"
 
 namespace pea {
@@ -254,10 +256,165 @@ __global__ __launch_bounds__(256) void bpr_train_final_kernel(int n_blocks, cons
     if (threadIdx.x == 0) loss[0] = -red[0];
 }
 
+// dst[id, col[p] + c] = sum over the positions k with ids[k] == id of src[k, p * R + c], added in increasing k: the
+// scatter of the batch's gradient rows into the node-indexed output-gradient buffer (autograd's index backward: torch
+// sorts the ids for this with ~25 launches for 12 k ids).  Two launches: (1) ONE workgroup groups the (id, position) keys
+// of the whole batch in LDS (<= 16384 keys: 128 KB), so the positions of a node become one run ordered by position;
+// (2) one wave per run adds the run's rows in that order, NB rows in flight, and writes the node's row.  Same additions in the same order as a sequential loop over the batch: bitwise reproducible,
+// no atomics.  ids < 0 sort to the end and are skipped.
+constexpr int kSortThreads = 1024;
+constexpr int kSortMax = 16384;
+constexpr int kBuckets = 2048;
+
+// Groups the batch's (id, position) keys: bucket = id % 2048 (LDS histogram + prefix sum; integer atomics only decide
+// scratch slots, never the result), then every key finds its rank inside its bucket by counting the smaller keys there
+// (buckets hold a handful of keys; a node named 500 times makes 500 threads read 500 keys each).  Output: the keys ordered
+// by (bucket, id, position): the positions of one node are one run, in position order.  Keys of ids < 0 go last (~0).
+__global__ __launch_bounds__(kSortThreads) void sort_ids_kernel(int n, const int64_t *__restrict__ ids,
+                                                                unsigned long long *__restrict__ sorted) {
+    unsigned long long *tmp = reinterpret_cast<unsigned long long *>(tsm);     // [n] keys in bucket order, unordered inside
+    __shared__ int start[kBuckets + 1], cursor[kBuckets];
+    __shared__ int wave_tot[kSortThreads / 64];
+    __shared__ int n_valid;
+    for (int b = threadIdx.x; b < kBuckets; b += kSortThreads) cursor[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kSortThreads) {
+        const int64_t id = ids[i];
+        if (id >= 0) atomicAdd(&cursor[(int)(id % kBuckets)], 1);
+    }
+    __syncthreads();
+    {   // exclusive prefix sum of the 2048 counts: 2 per thread, wave scan, then the 16 wave totals
+        const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+        const int c0 = cursor[2 * t], c1 = cursor[2 * t + 1];
+        int v = c0 + c1;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(v, off);
+            if (lane >= off) v += o;
+        }
+        if (lane == 63) wave_tot[wave] = v;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wave_tot[w];
+        const int excl = base + v - (c0 + c1);
+        start[2 * t] = excl;
+        start[2 * t + 1] = excl + c0;
+        if (t == kSortThreads - 1) {
+            start[kBuckets] = excl + c0 + c1;
+            n_valid = excl + c0 + c1;
+        }
+        __syncthreads();
+        cursor[2 * t] = 0;
+        cursor[2 * t + 1] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kSortThreads) {
+        const int64_t id = ids[i];
+        if (id < 0) continue;
+        const int b = (int)(id % kBuckets);
+        tmp[start[b] + atomicAdd(&cursor[b], 1)] = ((unsigned long long)id << 32) | (unsigned)i;
+    }
+    __syncthreads();
+    const int nv = n_valid;
+    for (int j = threadIdx.x; j < nv; j += kSortThreads) {
+        const unsigned long long key = tmp[j];
+        const int b = (int)((key >> 32) % kBuckets);
+        int rank = 0;
+        for (int r = start[b]; r < start[b + 1]; ++r) rank += tmp[r] < key;
+        sorted[start[b] + rank] = key;
+    }
+    for (int j = nv + threadIdx.x; j < n; j += kSortThreads) sorted[j] = ~0ull;
+}
+
+template <int V>   // float4 columns per lane: 1 for rows of <= 256 floats, else 4
+__global__ __launch_bounds__(256) void scatter_runs_kernel(int n, const unsigned long long *__restrict__ sorted,
+                                                           const float *__restrict__ src, int64_t ld_src, int W, int R,
+                                                           const ChanCols cols, float *__restrict__ dst, int64_t ld_dst) {
+    constexpr int NB = 32 / V;
+    const int lane = threadIdx.x & 63;
+    const int i0 = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i0 >= n) return;
+    const unsigned long long k0 = sorted[i0];
+    if (k0 == ~0ull) return;                                          // skipped ids (and everything after them)
+    const unsigned id = (unsigned)(k0 >> 32);
+    if (i0 > 0 && (unsigned)(sorted[i0 - 1] >> 32) == id) return;     // not the first position of this node's run
+    float4 acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = i0; i < n; i += NB) {
+        // the next NB sorted keys (one per lane), how many of them continue the run
+        const unsigned long long kk = (lane < NB && i + lane < n) ? sorted[i + lane] : ~0ull;
+        const unsigned long long same = __ballot(lane < NB && kk != ~0ull && (unsigned)(kk >> 32) == id);
+        const int cnt = __builtin_ctzll(~same);                        // leading run of set bits (lane 0 upwards)
+        float4 t[NB][V];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const unsigned pos = (unsigned)__shfl(kk, u < cnt ? u : 0);   // a slot past the run re-reads its first row, weight 0
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int c4 = 4 * (lane + 64 * v);
+                t[u][v] = c4 < W ? ld4t(src + (int64_t)pos * ld_src + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const float f = u < cnt ? 1.f : 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                acc[v] = make_float4(fmaf(f, t[u][v].x, acc[v].x), fmaf(f, t[u][v].y, acc[v].y), fmaf(f, t[u][v].z, acc[v].z),
+                                     fmaf(f, t[u][v].w, acc[v].w));
+        }
+        if (cnt < NB) break;
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int c4 = 4 * (lane + 64 * v);
+        if (c4 < W) *reinterpret_cast<float4 *>(dst + (int64_t)id * ld_dst + cols.c[c4 / R] + c4 % R) = acc[v];
+    }
+}
+
 }  // namespace
 }  // namespace pea
 
 using namespace pea;
+
+extern "C" size_t pea_rows_scatter_sum_workspace_bytes(int64_t n) { return n < 0 ? 0 : (size_t)n * 8 + 256; }
+
+extern "C" int pea_rows_scatter_sum(int64_t n, const int64_t *ids, const float *src, int64_t ld_src, int P, int R,
+                                    const int *col_of_channel_host, float *dst, int64_t ld_dst, void *workspace,
+                                    size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PEA_REQUIRE(n >= 0 && n <= kSortMax, PEA_ERR_ARG, "rows_scatter_sum: %lld positions (the batch is sorted in LDS: <= %d)",
+                (long long)n, kSortMax);
+    PEA_REQUIRE(P > 0 && P <= kMaxChannels && R > 0 && R % 4 == 0 && P * R <= 1024, PEA_ERR_ARG,
+                "rows_scatter_sum: P=%d R=%d (R a multiple of 4, P * R <= 1024)", P, R);
+    PEA_REQUIRE(ids && src && dst && col_of_channel_host && ld_src >= (int64_t)P * R && ld_src % 4 == 0 && ld_dst % 4 == 0,
+                PEA_ERR_ARG, "rows_scatter_sum: bad argument");
+    PEA_REQUIRE(workspace && workspace_bytes >= pea_rows_scatter_sum_workspace_bytes(n), PEA_ERR_NOMEM, "rows_scatter_sum: workspace too small");
+    if (n == 0) return PEA_OK;
+    ChanCols cols;
+    for (int p = 0; p < P; ++p) {
+        PEA_REQUIRE(col_of_channel_host[p] >= 0 && col_of_channel_host[p] % 4 == 0, PEA_ERR_ARG, "rows_scatter_sum: column %d", col_of_channel_host[p]);
+        cols.c[p] = col_of_channel_host[p];
+    }
+    unsigned long long *sorted = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+    static bool attr_set = false;
+    if (!attr_set) {
+        PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_ids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kSortMax * 8));
+        attr_set = true;
+    }
+    ProfScope ps("scatter_sum", stream, (double)n * P * R * 8.0);
+    hipLaunchKernelGGL(sort_ids_kernel, dim3(1), dim3(kSortThreads), (size_t)n * 8, stream, (int)n, ids, sorted);
+    PEA_HIP(hipGetLastError());
+    const int blocks = (int)((n + 3) / 4);
+    if (P * R > 256) {
+        hipLaunchKernelGGL(scatter_runs_kernel<4>, dim3(blocks), dim3(256), 0, stream, (int)n, sorted, src, ld_src, P * R, R, cols, dst, ld_dst);
+    } else {
+        hipLaunchKernelGGL(scatter_runs_kernel<1>, dim3(blocks), dim3(256), 0, stream, (int)n, sorted, src, ld_src, P * R, R, cols, dst, ld_dst);
+    }
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
 
 extern "C" size_t pea_bpr_train_workspace_bytes(int64_t B) {
     return B < 0 ? 0 : (size_t)((B + kTB - 1) / kTB + 4) * sizeof(float);

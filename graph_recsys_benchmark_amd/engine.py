@@ -494,6 +494,53 @@ def rank_eval(repr_, unids, cand, fc1_w, fc1_b, fc2_w, fc2_b):
     return scores, rank, auc, loss
 
 
+def bpr_train_raw(picked, att, fc1_w, fc1_b, fc2_w, fc2_b):
+    """One launch of csrc/bpr_train.hip + the two fixed-order reductions (pea_grad_weight): returns
+    (loss, grad_rows [3B, P*R], (d_att | None, d_fc1_w, d_fc1_b, d_fc2_w, d_fc2_b)) for picked [3B, P, R]."""
+    lib = _lib.require_device()
+    n3, p_, r_ = picked.shape
+    b = n3 // 3
+    rows = picked.detach()
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    dev = rows.device
+    keep = [t.detach().contiguous() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
+    att_c = att.detach().contiguous().view(-1) if att is not None else None
+    grad_rows = torch.empty((n3, p_ * r_), dtype=torch.float32, device=dev)
+    dhx = torch.empty((2 * b, r_ + 4), dtype=torch.float32, device=dev)
+    zx = torch.empty((2 * b, 3 * r_ + 4), dtype=torch.float32, device=dev)
+    p4 = (p_ + 3) // 4 * 4
+    dsc = torch.empty((n3, p4), dtype=torch.float32, device=dev) if att is not None else None
+    ws_bytes = int(lib.pea_bpr_train_workspace_bytes(b))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    _lib.check(lib.pea_bpr_train(b, p_, r_, _lib.ptr(rows), p_ * r_, _lib.ptr(att_c), _lib.ptr(keep[0]), _lib.ptr(keep[1]),
+                                 _lib.ptr(keep[2]), _lib.ptr(keep[3]), _lib.ptr(loss), _lib.ptr(grad_rows), _lib.ptr(dhx),
+                                 _lib.ptr(zx), _lib.ptr(dsc), _lib.ptr(ws), ws_bytes, _lib.current_stream()))
+    g = grad_weight([(dhx, zx)])[0]                    # [R + 4, 3R + 4]
+    d_att = None
+    if att is not None:
+        full = grad_weight([(dsc, rows.view(n3, p_ * r_))])[0]      # [P4, P * R]: the diagonal R-blocks are d att[p]
+        d_att = torch.stack([full[q, q * r_:(q + 1) * r_] for q in range(p_)]).view(att.shape)
+    return loss, grad_rows, (d_att, g[:r_, :2 * r_], g[:r_, 3 * r_], g[r_, 2 * r_:3 * r_].view(fc2_w.shape),
+                             g[r_, 3 * r_].view(fc2_b.shape))
+
+
+def rows_scatter_sum(ids, src, num_channels, repr_dim, col_of_channel, dst):
+    """dst[id, col_of_channel[p] + c] = sum_{k: ids[k] == id} src[k, p * R + c] in increasing k (ids < 0 skipped): the
+    deterministic index backward of rows = stack[ids] into the node-indexed gradient buffer (an LDS sort of the batch's
+    ids + one wave per node); at most ROWS_SCATTER_MAX positions."""
+    lib = _lib.require_device()
+    cols = (C.c_int * num_channels)(*[int(c) for c in col_of_channel])
+    ws_bytes = int(lib.pea_rows_scatter_sum_workspace_bytes(ids.numel()))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
+    _lib.check(lib.pea_rows_scatter_sum(ids.numel(), _lib.ptr(ids), _lib.ptr(src), src.stride(0), int(num_channels), int(repr_dim),
+                                        cols, _lib.ptr(dst), dst.stride(0), _lib.ptr(ws), ws_bytes, _lib.current_stream()))
+
+
+ROWS_SCATTER_MAX = 16384      # positions pea_rows_scatter_sum sorts in LDS (a BPR batch of up to 5461 triples)
+
+
 class _BprTrainLoss(torch.autograd.Function):
     """loss = -sum_b log sigmoid(score(u_b, i+_b) - score(u_b, i-_b)) over the fused rows of the batch's stack rows, and its
     whole backward, in one HIP launch (csrc/bpr_train.hip) + two fixed-order reductions for the parameter gradients
@@ -502,33 +549,8 @@ class _BprTrainLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, picked, att, fc1_w, fc1_b, fc2_w, fc2_b):
-        lib = _lib.require_device()
-        n3, p_, r_ = picked.shape
-        b = n3 // 3
-        rows = picked.detach()
-        if not rows.is_contiguous():
-            rows = rows.contiguous()
-        dev = rows.device
-        keep = [t.detach().contiguous() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
-        att_c = att.detach().contiguous().view(-1) if att is not None else None
-        grad_rows = torch.empty((n3, p_ * r_), dtype=torch.float32, device=dev)
-        dhx = torch.empty((2 * b, r_ + 4), dtype=torch.float32, device=dev)
-        zx = torch.empty((2 * b, 3 * r_ + 4), dtype=torch.float32, device=dev)
-        p4 = (p_ + 3) // 4 * 4
-        dsc = torch.empty((n3, p4), dtype=torch.float32, device=dev) if att is not None else None
-        ws_bytes = int(lib.pea_bpr_train_workspace_bytes(b))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.check(lib.pea_bpr_train(b, p_, r_, _lib.ptr(rows), p_ * r_, _lib.ptr(att_c), _lib.ptr(keep[0]), _lib.ptr(keep[1]),
-                                     _lib.ptr(keep[2]), _lib.ptr(keep[3]), _lib.ptr(loss), _lib.ptr(grad_rows), _lib.ptr(dhx),
-                                     _lib.ptr(zx), _lib.ptr(dsc), _lib.ptr(ws), ws_bytes, _lib.current_stream()))
-        g = grad_weight([(dhx, zx)])[0]                    # [R + 4, 3R + 4]
-        d_att = None
-        if att is not None:
-            full = grad_weight([(dsc, rows.view(n3, p_ * r_))])[0]      # [P4, P * R]: the diagonal R-blocks are d att[p]
-            d_att = torch.stack([full[q, q * r_:(q + 1) * r_] for q in range(p_)]).view(att.shape)
-        ctx.grads = (grad_rows.view(n3, p_, r_), d_att, g[:r_, :2 * r_], g[:r_, 3 * r_], g[r_, 2 * r_:3 * r_].view(fc2_w.shape),
-                     g[r_, 3 * r_].view(fc2_b.shape))
+        loss, grad_rows, head = bpr_train_raw(picked, att, fc1_w, fc1_b, fc2_w, fc2_b)
+        ctx.grads = (grad_rows.view(picked.shape),) + head
         return loss
 
     @staticmethod

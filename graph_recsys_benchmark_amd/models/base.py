@@ -17,7 +17,7 @@ import torch
 from torch.nn import Parameter
 
 from .. import engine as _engine
-from ..autograd import PEAStackFunction, StackOptions
+from ..autograd import PEALossFunction, PEAStackFunction, StackOptions
 from ..nn.inits import glorot
 
 
@@ -234,7 +234,13 @@ class PEABaseRecsysModel(GraphRecsysModel):
         ids = t[:, :3].reshape(-1)                  # the stack is read at the batch's rows only: tell the backward
         opts = StackOptions(fuse_att=self.att.detach().reshape(eng.P, eng.repr_dim) if self.channel_aggr == 'att' else None,
                             read_ids=ids)
-        stack = PEAStackFunction.apply(eng, self.x, eng.slots, opts, *flat)
+        if _engine.bpr_train_supported(eng.P, eng.repr_dim) and ids.numel() <= _engine.ROWS_SCATTER_MAX:
+            # one autograd node for the whole step: conv stack + the batch's rows + fusion / scorer / loss, all HIP
+            loss = PEALossFunction.apply(eng, self.x, eng.slots, opts, ids, self.att if self.channel_aggr == 'att' else None,
+                                         self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, *flat)
+            self.cached_repr, self._repr_partial = opts.fused, eng.sharded
+            return loss
+        stack = PEAStackFunction.apply(eng, self.x, eng.slots, opts, *flat)      # repr_dim > 32 or > 5461 triples: torch ops
         self.cached_repr, self._repr_partial = opts.fused, eng.sharded
         b = t.shape[0]
         if eng.sharded:
@@ -244,11 +250,7 @@ class PEABaseRecsysModel(GraphRecsysModel):
             picked = _ShardedRows.apply(stack.view(stack.shape[0], -1), ids, eng.plan.layout).view(-1, eng.P, eng.repr_dim)
         else:
             picked = stack[ids]
-        if _engine.bpr_train_supported(eng.P, eng.repr_dim):
-            # fusion + scorer + loss of the batch's rows, forward and backward, in one HIP launch (csrc/bpr_train.hip)
-            return _engine.bpr_train_loss(picked, self.att if self.channel_aggr == 'att' else None, self.fc1.weight,
-                                          self.fc1.bias, self.fc2.weight, self.fc2.bias)
-        rows = self._fuse_torch(picked).view(b, 3, -1)   # repr_dim > 32: the same head in torch ops on the GPU
+        rows = self._fuse_torch(picked).view(b, 3, -1)
 
         def score(i):
             return self.fc2(torch.relu(self.fc1(torch.cat([rows[:, 0], rows[:, i]], dim=-1))))

@@ -344,12 +344,20 @@ int pea_entity_reg(int64_t B, int emb_dim, int64_t num_nodes, const float *x, in
  *                                                     d fc2.weight = G[R, 2R:3R],  d fc2.bias = G[R, 3R]
  *   dsc [3B, P4] (P4 = P rounded up to 4; 'att' only):  d att[p, :] = (dsc^T rows)[p, p*R:(p+1)*R]
  * repr_dim R: a multiple of 4, <= 32 (pea_bpr_train_supported).  No atomics, fixed reduction order.
+ * pea_rows_scatter_sum: dst[id, col_of_channel[p] + c] = sum over the positions k with ids[k] == id of src[k, p*R + c],
+ * added in increasing k (the index backward of rows = stack[ids]: the batch's gradient rows into the node-indexed
+ * output-gradient buffer: the batch's (id, position) keys are sorted in LDS by one workgroup, then one wave per node adds
+ * its rows in position order; ids < 0 are skipped; n <= 16384, P*R <= 1024).
  * ---------------------------------------------------------------------------------------------- */
 size_t pea_bpr_train_workspace_bytes(int64_t B);
 int pea_bpr_train_supported(int P, int R);
 int pea_bpr_train(int64_t B, int P, int R, const float *rows, int64_t ld_rows, const float *att, const float *fc1_w,
                   const float *fc1_b, const float *fc2_w, const float *fc2_b, float *out_loss, float *grad_rows,
                   float *dhx, float *zx, float *dsc, void *workspace, size_t workspace_bytes, void *stream);
+size_t pea_rows_scatter_sum_workspace_bytes(int64_t n);
+int pea_rows_scatter_sum(int64_t n, const int64_t *ids, const float *src, int64_t ld_src, int P, int R,
+                         const int *col_of_channel_host, float *dst, int64_t ld_dst, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange helpers (one process per GPU; the collectives themselves are RCCL calls made by the host

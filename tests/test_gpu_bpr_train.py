@@ -68,14 +68,14 @@ def test_training_loss_of_a_model_uses_the_hip_head_and_matches_the_torch_head(a
                                        rng.integers(*blocks['i'], size=200)], axis=1).astype(np.int64)).cuda()
     model.train()
     calls = []
-    orig_loss = engine.bpr_train_loss
-    engine.bpr_train_loss = lambda *a: (calls.append(1), orig_loss(*a))[1]
+    orig_raw = engine.bpr_train_raw
+    engine.bpr_train_raw = lambda *a: (calls.append(1), orig_raw(*a))[1]
     try:
         model.zero_grad()
         loss = model.loss(batch)
         loss.backward()
     finally:
-        engine.bpr_train_loss = orig_loss
+        engine.bpr_train_raw = orig_raw
     assert calls, 'the training loss did not go through csrc/bpr_train.hip'
     got = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
     orig = engine.bpr_train_supported
@@ -93,3 +93,38 @@ def test_training_loss_of_a_model_uses_the_hip_head_and_matches_the_torch_head(a
             continue
         scale = float(v.grad.abs().max())
         assert float((got[k] - v.grad).abs().max()) <= 2e-4 * scale + 1e-7, k
+
+
+def test_rows_scatter_sum_accumulates_duplicates_in_position_order():
+    """pea_rows_scatter_sum against a sequential float32 accumulation in position order: bit-exact (the same additions in
+    the same order), with heavy duplication, skipped (negative) ids and a channel -> column permutation; and against a
+    float64 sum within fp32 rounding."""
+    import numpy as np
+    from graph_recsys_benchmark_amd import engine
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(5)
+    for n, p, r, nodes in ((1000, 9, 16, 50), (4099, 3, 8, 4000), (1, 1, 4, 3), (12288, 9, 16, 6000), (700, 20, 16, 9), (16384, 2, 4, 100)):
+        ids = rng.integers(0, nodes, size=n).astype(np.int64)
+        ids[rng.random(n) < 0.1] = -1
+        if n > 10:
+            ids[:7] = ids[7]                                     # a run of duplicates at the front
+        src = rng.standard_normal((n, p * r)).astype(np.float32)
+        perm = rng.permutation(p)
+        cols = [int(perm[q]) * r for q in range(p)]
+        ld = p * r + 4
+        want = np.full((nodes, ld), 7.0, dtype=np.float32)      # rows / columns nobody writes keep their value
+        want64 = want.astype(np.float64)
+        for i in np.unique(ids[ids >= 0]):
+            pos = np.nonzero(ids == i)[0]
+            acc = src[pos[0]].copy()
+            for q in pos[1:]:
+                acc = acc + src[q]
+            tot = src[pos].astype(np.float64).sum(axis=0)
+            for c in range(p):
+                want[i, cols[c]:cols[c] + r] = acc[c * r:(c + 1) * r]
+                want64[i, cols[c]:cols[c] + r] = tot[c * r:(c + 1) * r]
+        dst = torch.full((nodes, ld), 7.0, dtype=torch.float32, device=dev)
+        engine.rows_scatter_sum(torch.from_numpy(ids).to(dev), torch.from_numpy(src).to(dev), p, r, cols, dst)
+        got = dst.cpu().numpy()
+        assert np.array_equal(got, want), (n, p, r, float(np.abs(got - want).max()))
+        assert np.abs(got - want64).max() <= 1e-5 * max(1.0, np.abs(want64).max())
