@@ -61,7 +61,7 @@ def main(root):
 
 
 BENCH_NAME = {'gemm_persist_k32': 'gemm_mfma_shared', 'gemm_skinny_k4': 'gemm_mfma_narrow',   # names bench.py prints
-              'gemm_persist_k64': 'gemm_mfma_shared', 'gemm_skinny_k8': 'gemm_mfma_narrow', 'mlp2_kernel': 'mlp2_fused'}
+              'gemm_persist_k64': 'gemm_mfma_shared', 'gemm_skinny_k8': 'gemm_mfma_narrow', 'mlp2_kernel': 'mlp2_fused', 'mlp2_sage_kernel': 'mlp2_fused'}
 
 
 def merge_traffic(res, key, source):
