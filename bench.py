@@ -214,8 +214,15 @@ def gather_tier(table_bytes, l2_hit_rate, achieved=None, hit_from=None):
         if l2_hit_rate >= 0.5:
             return 'l2', GATHER_CEILING_GBS['l2'], src
         blend = 1.0 / (l2_hit_rate / GATHER_CEILING_GBS['l2'] + (1.0 - l2_hit_rate) / GATHER_CEILING_GBS[below])
-        return 'l2+' + below, blend, ('%s, table %.0f MB: harmonic blend of the L2 and %s gather ceilings'
-                                      % (src, table_bytes / 1e6, below))
+        why = '%s, table %.0f MB: harmonic blend of the L2 and %s gather ceilings' % (src, table_bytes / 1e6, below)
+        if achieved is not None and achieved > blend:
+            # the guide's miss-tier figure (measured with its own row width) is beaten by these rows: price the misses at
+            # the hardware rate of that tier instead (HBM: the 8 TB/s pin rate; Infinity Cache: the L2 ceiling)
+            miss = HBM_PEAK_GBS if below == 'hbm' else GATHER_CEILING_GBS['l2']
+            blend = 1.0 / (l2_hit_rate / GATHER_CEILING_GBS['l2'] + (1.0 - l2_hit_rate) / miss)
+            why += ('; measured %.0f GB/s is above that blend, so the misses are priced at %s instead'
+                    % (achieved, 'the 8 TB/s HBM peak' if below == 'hbm' else 'the L2 ceiling'))
+        return 'l2+' + below, blend, why
     if table_bytes <= L2_BYTES // 8:
         return 'l2', GATHER_CEILING_GBS['l2'], 'table %.1f MB fits one XCD L2 (no PMC profile for this preset / kind)' % (table_bytes / 1e6)
     order = ['hbm', 'infinity_cache', 'l2']
