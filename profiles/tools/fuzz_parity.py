@@ -1,6 +1,8 @@
 """Randomised parity sweep (GPU box): random heterogeneous graphs (skewed degrees, hubs, multi-edges, empty relations),
 random widths / heads / step counts, optionally with the source-sliced layout forced on small graphs, HIP path against
-the CPU oracle (and float64 where fp32 orders legitimately differ).  python profiles/tools/fuzz_parity.py [N] [seed]"""
+the CPU oracle (and float64 where fp32 orders legitimately differ).  python profiles/tools/fuzz_parity.py [N] [seed]
+FUZZ_TWOSTEP=1: only configurations the two-step inference schedule takes (every channel 2 steps, one head, emb / hidden
+64 or 128, repr <= 32 -- <= 16 for SAGE): csrc/mlp2.hip and the first-layer aggregation of x."""
 import os
 import sys
 import traceback
@@ -20,6 +22,11 @@ def one(rng, i):
     hidden = 4 * int(rng.integers(1, 33))
     repr_dim = 4 * int(rng.integers(1, 9))
     n_ch = int(rng.integers(1, 6))
+    twostep = os.environ.get('FUZZ_TWOSTEP') == '1'
+    if twostep:
+        heads, emb, hidden = 1, int(rng.choice([64, 128])), int(rng.choice([64, 128]))
+        repr_dim = 4 * int(rng.integers(1, 5 if kind == 'sage' else 9))
+        n_ch = int(rng.integers(1, 12))
     rels = []
     for _ in range(int(rng.integers(1, 4))):
         e = int(rng.choice([0, 5, 200, 3000, 30000]))
@@ -30,7 +37,7 @@ def one(rng, i):
         rels.append(np.stack([rng.integers(0, n, e), dst]).astype(np.int64))
     steps, edges = [], []
     for _ in range(n_ch):
-        s = int(rng.integers(1, 4))
+        s = 2 if twostep else int(rng.integers(1, 4))
         if kind == 'gat' and heads > 1 and s == 1:
             s = 2                                          # a 1-step GAT channel only stacks with one head (reference)
         steps.append(s)
