@@ -56,7 +56,7 @@ def test_training_loss_of_a_model_uses_the_hip_head_and_matches_the_torch_head(a
     float64 check of the whole step is tests/test_gpu_backward.py."""
     import numpy as np
     from graph_recsys_benchmark_amd import engine
-    from tests.helpers import build_model, random_hin, random_state_dict
+    from helpers import build_model, random_hin, random_state_dict
     n, blocks, rel = random_hin(47, n_user=900, n_item=300, n_attr=20, e_u2i=9000, e_attr=800)
     u2i, a2i = rel['u2i'], rel['a2i']
     flip = lambda e: np.ascontiguousarray(e[::-1])
