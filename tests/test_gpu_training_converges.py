@@ -32,7 +32,7 @@ def _train(model, batch, steps):
         loss = model.loss(batch)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     return losses
 
 
