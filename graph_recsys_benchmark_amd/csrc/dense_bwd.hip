@@ -96,6 +96,72 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
     }
 }
 
+// stage 1 for full 64 x 64 blocks (the first layer's dW = dT_0^T x: nine of them): the dword loads above fetch 64-byte
+// pieces (one column per lane) -- 4.9 M load instructions for 1.26 GB.  Here the workgroup streams its row part in chunks
+// of 32 rows with float4 loads (a whole 256-byte row piece per 16 lanes) into a double-buffered LDS image, and wave w
+// computes the four 16 x 16 tiles of tile row w from it (operands read back as dwords: row stride 80 floats = two lanes
+// per bank, the minimum for 64 lanes); no cross-wave reduction, the record layout of stage 2 is unchanged.  Rows are
+// added in the same order as above within a part (the k index of the MFMA steps runs over the rows in order), so the
+// results agree with the dword version bit for bit per tile... up to which wave owned which rows there: that version
+// summed four interleaved row subsets and added them; this one adds all rows of the part in order.
+constexpr int kGwLd = 80;
+__global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
+    const int64_t n_rows = M.n;
+    __shared__ float As[2][32][kGwLd], Bs[2][32][kGwLd];
+    const GwJob &J = Jb.j[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int64_t chunk = ((n_rows + kGwParts - 1) / kGwParts + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = min(n_rows, r0 + chunk);
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // loader role: thread t moves float4 column (t % 16) of rows (t / 16) and (t / 16) + 16 of the chunk, both operands
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    float4 pa[2], pb[2];
+    auto fetch = [&](int64_t base) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t n = base + lr + 16 * u;
+            const int64_t nr = M.row(n < r1 ? n : r0);
+            const bool ok = n < r1 && nr < M.N;
+            const int64_t nc = ok ? nr : 0;
+            const float4 va = *reinterpret_cast<const float4 *>(J.a + nc * J.lda + lc);
+            const float4 vb = *reinterpret_cast<const float4 *>(J.b + nc * J.ldb + lc);
+            pa[u] = ok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[u] = ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<float4 *>(&As[buf][lr + 16 * u][lc]) = pa[u];
+            *reinterpret_cast<float4 *>(&Bs[buf][lr + 16 * u][lc]) = pb[u];
+        }
+    };
+    if (r0 < r1) {
+        fetch(r0);
+        stash(0);
+    }
+    int buf = 0;
+    for (int64_t base = r0; base < r1; base += 32, buf ^= 1) {
+        __syncthreads();
+        if (base + 32 < r1) fetch(base + 32);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float av = As[buf][4 * s + kq][16 * wave + i];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[buf][4 * s + kq][16 * nt + i], acc[nt], 0, 0, 0);
+        }
+        if (base + 32 < r1) stash(buf ^ 1);
+    }
+    float *dst = partial + ((size_t)blockIdx.y * kGwParts + blockIdx.x) * (16 * 256);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dst[((wave * 4 + nt) * 4 + v) * 64 + lane] = acc[nt][v];
+}
+
 // stage 2: out = sum over parts, part order.  Element e of a record: tile (mt, nt), register v, lane l ->
 // row 16 mt + 4 (l / 16) + v, column 16 nt + l % 16.
 template <int MT, int NT>
@@ -115,7 +181,15 @@ template <int MT, int NT>
 int launch_gw(const GwBatch &Jb, const RowMap &rows, float *partial, double bytes, hipStream_t stream) {
     {
         ProfScope ps("grad_weight", stream, bytes);
-        hipLaunchKernelGGL((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
+        bool full = MT == 4 && NT == 4;   // every block 64 x 64 with float4-addressable operands: the LDS-staged kernel
+        for (int q = 0; q < Jb.n && full; ++q)
+            full = Jb.j[q].ma == 64 && Jb.j[q].nb == 64 && Jb.j[q].lda % 4 == 0 && Jb.j[q].ldb % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(Jb.j[q].a) | reinterpret_cast<uintptr_t>(Jb.j[q].b)) % 16 == 0;
+        if (full) {
+            hipLaunchKernelGGL(gw_stage1_lds, dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
+        } else {
+            hipLaunchKernelGGL((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
+        }
         PEA_HIP(hipGetLastError());
     }
     ProfScope ps("grad_weight_sum", stream);

@@ -211,6 +211,83 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmBatch Bt, cons
     }
 }
 
+extern __shared__ float g_lds[];
+
+// Deep k (K > 128: the first layer's input gradient dx = dT_0 W_cat, K = sum of the channels' hidden widths), outputs up
+// to 32 * NCT columns: the staged kernel above walks (column tile, k chunk) stages and so reads every A chunk once per
+// column tile and takes a barrier per stage; here a stage is one 128-deep k chunk for ALL column tiles (NCT accumulator
+// tiles per wave): A is read once, half the barriers, and the next chunk's A fragment and B tile are in flight during the
+// MFMAs.  Same k order per output as the staged kernel (chunks in order, within a chunk kk = 0..63 with the two k-halves
+// on the two lane halves).
+template <int NCT>
+__global__ __launch_bounds__(256) void gemm_deep_kernel(const GemmBatch Bt, const int *__restrict__ rows, int64_t n_rows) {
+    constexpr int KH = 64, W = 32 * NCT, NLD = 32 * W / 256;   // float4 loads per thread per B stage (128 x W floats)
+    const GemmJob &J = Bt.j[blockIdx.y];
+    if (J.rows) {
+        rows = J.rows;
+        n_rows = J.n_rows;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * 32;
+    const int64_t grow = row0 + r;
+    const bool rv = grow < n_rows;
+    const int64_t srow = rv ? (rows ? (int64_t)rows[grow] : grow) : 0;
+    const int K = J.K1 + J.K2;
+    const int nkc = (K + 2 * KH - 1) / (2 * KH);
+    int orow[16];
+    const unsigned valid = load_orow(rows, row0, h, n_rows, orow);
+    float4 pre[NLD];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            const int k = kc * 2 * KH + idx / (W / 4), c = (idx % (W / 4)) * 4;
+            pre[i] = (k < K && c < J.ldb) ? ld4(J.B + (size_t)k * J.ldb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<float4 *>(g_lds + ((size_t)buf * 2 * KH + idx / (W / 4)) * W + (idx % (W / 4)) * 4) = pre[i];
+        }
+    };
+    float a[KH], a2[KH];
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+    fetch(0);
+    stash(0);
+    load_a<KH>(J, srow, rv, h * KH, a);
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+        const bool more = kc + 1 < nkc;
+        if (more) {
+            fetch(kc + 1);
+            load_a<KH>(J, srow, rv, (kc + 1) * 2 * KH + h * KH, a2);
+        }
+        const float *bs = g_lds + ((size_t)(kc & 1) * 2 * KH + h * KH) * W + r;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bs[kk * W + 32 * ct], acc[ct], 0, 0, 0);
+        if (more) {
+            stash((kc + 1) & 1);
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) a[kk] = a2[kk];
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int c = 32 * ct + r;
+        const OutCol o = find_out(J, c);
+        const float bias = (J.bias && c < J.n_out) ? J.bias[c] : 0.f;
+        store_tile(acc[ct], o, bias, rows != nullptr, orow, valid, row0, h);
+    }
+}
+
 // Persistent variant (the default): every workgroup first copies the WHOLE k-major B of all its jobs into LDS
 // (the 9 first-layer transforms of the MovieLens model are one 64 x 596 block = 149 KiB of the CU's 160 KiB), then its
 // 16 waves walk (job, 32-row tile, column group) items with no barrier at all: A fragment from global, B fragment
@@ -224,8 +301,6 @@ struct PersistArgs {
     int lds_ld[kMaxBatch];
     int n_tiles[kMaxBatch];        // 32-row tiles of job j (jobs may carry their own row lists)
 };
-
-extern __shared__ float g_lds[];
 
 template <int KH, bool LISTED>
 __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(const GemmBatch Bt, const PersistArgs Pa, const int *__restrict__ rows,
@@ -764,7 +839,26 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                     for (int q = 0; q < Bt.n; ++q) max_rows = std::max<int64_t>(max_rows, Bt.j[q].rows ? Bt.j[q].n_rows : 0);
                     dim3 grid((unsigned)((max_rows + 127) / 128), (unsigned)Bt.n);
                     ProfScope ps("gemm_mfma_deep", stream, bytes);
-                    hipLaunchKernelGGL(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows);
+                    int max_out = 0;
+                    for (int q = 0; q < Bt.n; ++q) max_out = std::max(max_out, Bt.j[q].n_out);
+                    const char *env = getenv("PEA_DEEP_STAGED");   // A/B switch: the per-column-tile staged kernel
+                    if (max_out <= 128 && !(env && atoi(env) != 0)) {
+                        const int nct = max_out <= 32 ? 1 : max_out <= 64 ? 2 : 4;
+                        const size_t lds_deep = (size_t)2 * 128 * 32 * nct * sizeof(float);
+                        static bool attr_set = false;
+                        if (!attr_set) {
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_deep_kernel<2>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 64 * 4);
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_deep_kernel<4>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 * 4);
+                            attr_set = true;
+                        }
+                        if (nct == 1) hipLaunchKernelGGL(gemm_deep_kernel<1>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
+                        else if (nct == 2) hipLaunchKernelGGL(gemm_deep_kernel<2>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
+                        else hipLaunchKernelGGL(gemm_deep_kernel<4>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
+                    } else {
+                        hipLaunchKernelGGL(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows);
+                    }
                     if (hipGetLastError() != hipSuccess) rc = PEA_ERR_HIP;
                 }
                 Bt.n = 0;
