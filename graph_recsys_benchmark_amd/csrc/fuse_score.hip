@@ -222,25 +222,8 @@ __global__ __launch_bounds__(256) void rank_kernel(int64_t U, int C, int R, int6
     float pos = 0.f;
     int higher = 0, gt = 0;
     float lsum = 0.f;
-    // the reference's repr_dim: the user's half of every fc1 unit is the same for all C candidates of the user, so it is
-    // summed once (the same additions in the same order as mlp_score_reg, which starts every unit with the user half:
-    // scores stay bit-identical to pea_predict / pea_bpr_score) and a candidate costs the item half only
-    float pu[16];
-    if (R == 16) {
-        float4 ur[4];
-        load_row<4>(repr + u * R, ur);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float *w = w1 + k * 32;
-            float a = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 wu = ld4(w + 4 * c);
-                a += (ur[c].x * wu.x + ur[c].y * wu.y) + (ur[c].z * wu.z + ur[c].w * wu.w);
-            }
-            pu[k] = a;
-        }
-    }
+    float4 ur[4];
+    if (R == 16) load_row<4>(repr + u * R, ur);   // the reference's repr_dim: the user's row stays in registers
     for (int base = 0; base < C; base += kWave) {
         const int c = base + lane;
         float sc = 0.f;
@@ -254,20 +237,7 @@ __global__ __launch_bounds__(256) void rank_kernel(int64_t U, int C, int R, int6
                 if (R == 16) {   // same arithmetic, same order as mlp_score (rows held in registers)
                     float4 ir[4];
                     load_row<4>(repr + i * R, ir);
-                    float o = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const float *w = w1 + k * 32 + 16;
-                        float a = pu[k];
-#pragma unroll
-                        for (int c4 = 0; c4 < 4; ++c4) {
-                            const float4 wi = ld4(w + 4 * c4);
-                            a += (ir[c4].x * wi.x + ir[c4].y * wi.y) + (ir[c4].z * wi.z + ir[c4].w * wi.w);
-                        }
-                        a += b1[k];
-                        o = fmaf(fmaxf(a, 0.f), w2[k], o);
-                    }
-                    sc = o + fc2_b[0];
+                    sc = mlp_score_reg<4>(ur, ir, w1, b1, w2, fc2_b[0]);
                 } else {
                     sc = mlp_score(repr + u * R, repr + i * R, R, w1, b1, w2, fc2_b[0]);
                 }
