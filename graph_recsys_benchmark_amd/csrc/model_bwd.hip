@@ -140,8 +140,8 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         const int rr = m->reverse_of[(size_t)g.rel];
         PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", g.rel);
         Relation &R = plan->rels[(size_t)g.rel], &Rr = plan->rels[(size_t)rr];
-        PEA_REQUIRE(Rr.n_slots * partial_record_floats(g.W, g.F) <= m->partial_floats, PEA_ERR_NOMEM,
-                    "backward: hub partial buffer too small for the reversed relation");
+        PEA_REQUIRE(g.partial_off + (size_t)std::max(R.n_slots, Rr.n_slots) * partial_record_floats(g.W, g.F) <= m->partial_floats,
+                    PEA_ERR_NOMEM, "backward: hub partial buffer too small for relation %d and its reverse", g.rel);
         float *G = g.last ? dX + g.out_col : dO + g.out_col;
         const float *Out = g.last ? X + g.out_col : O + g.out_col;
         const int ldg = g.last ? m->ld_x : L.ld_o;
@@ -151,7 +151,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         a.F = g.F;
         a.neg_slope = d.negative_slope;
         a.self_loop = loops ? 1 : 0;
-        a.partial = partial;  // one group at a time below (the buffer is reused)
+        a.partial = partial + g.partial_off;  // every group its own region (sized for the relation and its reverse: slots_of)
         if (d.kind == PEA_KIND_GCN) {
             const bool fc = d.gcn_deg_from_col != 0;
             PEA_TRY(ensure_dinv(plan, g.rel, fc, stream));
@@ -164,7 +164,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             a.dinv_self = a.dinv;
             a.out = dT + g.col;
             a.ld_out = L.ld_t;
-            if (part_b) PEA_TRY(launch_aggregate(AGG_GCN, &a, 1, stream));
+            if (part_b) gsrc.push_back(a);
             continue;
         }
         a.att_src = pack + L.att_src_off + g.col;
@@ -197,7 +197,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             D.short_rows = R.short_rows + R.n_short0;
             D.n_short = R.n_short - R.n_short0;
         }
-        if (part_a) PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, &D, 1, stream));
+        if (part_a) gd.push_back(D);
         // S pass: source rows = destination rows of the reversed relation, gathers g_i and the side records
         AggGroup S = a;
         fill_lists(S, Rr);
@@ -211,7 +211,16 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         S.out = dT + g.col;
         S.ld_out = L.ld_t;
         S.deg0_self = loops ? R.deg0 : nullptr;
-        if (part_b) PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, &S, 1, stream));
+        if (part_b) gsrc.push_back(S);
+    }
+    // all groups of the level side by side in one set of launches per pass (the S pass of a group reads what the D pass
+    // of the same group wrote: every D launch precedes every S launch on the stream)
+    for (size_t b = 0; b < gd.size(); b += kMaxAggGroups)
+        PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, gd.data() + b, (int)std::min<size_t>(kMaxAggGroups, gd.size() - b), stream));
+    for (size_t b = 0; b < gsrc.size(); b += kMaxAggGroups) {
+        const int nb = (int)std::min<size_t>(kMaxAggGroups, gsrc.size() - b);
+        if (d.kind == PEA_KIND_GCN) PEA_TRY(launch_aggregate(AGG_GCN, gsrc.data() + b, nb, stream));
+        else PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, gsrc.data() + b, nb, stream));
     }
     // Gradient reductions, one launch per run of groups whose columns (and heads) are contiguous:
     //   d bias[c] = sum_n g[n, c];   d att_j[c] = sum_n d a_src[n, head(c)] T[n, c];   d att_i likewise with d a_dst
