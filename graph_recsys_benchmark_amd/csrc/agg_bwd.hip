@@ -106,10 +106,8 @@ __device__ __forceinline__ void finish_s(const AggGroup &P, const RowS &r, int r
 
 // ------------------------------------------------------------------------------------------------ short rows
 template <int G, int MODE, int F4T>
-__global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
-    const int gi = find_group(L);
-    const AggGroup &P = L.g[gi];
-    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / G) + (int)threadIdx.x / G;
+__device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk) {
+    const int item = blk * (kBlock / G) + (int)threadIdx.x / G;
     const int sl = (int)threadIdx.x % G, lane = (int)threadIdx.x % kWave;
     const bool valid = item < P.n_short;
     const int row = valid ? P.short_rows[item] : 0;
@@ -192,12 +190,10 @@ __global__ __launch_bounds__(kBlock) void bwd_short_kernel(const AggLaunch L) {
 
 // ------------------------------------------------------------------------------------------------ long rows / hub chunks
 template <int G, int MODE, int F4T>
-__global__ __launch_bounds__(kBlock) void bwd_long_kernel(const AggLaunch L) {
+__device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) {
     constexpr int NSG = kWave / G, U = 4;
-    const int gi = find_group(L);
-    const AggGroup &P = L.g[gi];
     const int lane = (int)threadIdx.x % kWave;
-    const int item = ((int)blockIdx.x - L.blk_start[gi]) * (kBlock / kWave) + (int)threadIdx.x / kWave;
+    const int item = blk * (kBlock / kWave) + (int)threadIdx.x / kWave;
     if (item >= P.n_long) return;
     const LongItem it = P.long_items[item];
     if (it.slot == -2) return;
@@ -293,6 +289,21 @@ __global__ __launch_bounds__(kBlock) void bwd_long_kernel(const AggLaunch L) {
     }
 }
 
+// One launch per pass and lane width, like the forward's agg_rows_kernel: workgroups [0, n_long_blocks) take the long rows
+// and hub chunks, the rest the short rows (they fill the machine while the last long items drain).
+template <int G, int MODE, int F4T>
+__global__ __launch_bounds__(kBlock) void bwd_rows_kernel(const AggLaunch L) {
+    if ((int)blockIdx.x >= L.n_long_blocks) {
+        const int b = (int)blockIdx.x - L.n_long_blocks;
+        int gi = 0;
+        while (gi + 1 < L.n_groups && b >= L.blk_short[gi + 1]) ++gi;
+        bwd_short_rows<G, MODE, F4T>(L.g[gi], b - L.blk_short[gi]);
+        return;
+    }
+    const int gi = find_group(L);
+    bwd_long_item<G, MODE, F4T>(L.g[gi], (int)blockIdx.x - L.blk_start[gi]);
+}
+
 // ------------------------------------------------------------------------------------------------ hub rows
 template <int G, int MODE, int F4T>
 __global__ __launch_bounds__(kBlock) void bwd_merge_kernel(const AggLaunch L) {
@@ -360,24 +371,43 @@ template <int G, int MODE, int F4T>
 int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
     const char *nm = MODE == AGG_GAT_BWD_D ? "gat_bwd_dst" : "gat_bwd_src";
     AggLaunch L;
-    for (int pass = 0; pass < 3; ++pass) {
+    {   // long rows + hub chunks first, short rows behind them, one launch
+        L.n_groups = 0;
+        int blocks = 0, sblocks = 0;
+        for (int i = 0; i < n_sel; ++i) {
+            const AggGroup &g = base.g[sel[i]];
+            if (g.n_short <= 0 && g.n_long <= 0) continue;
+            L.blk_start[L.n_groups] = blocks;
+            L.blk_short[L.n_groups] = sblocks;
+            L.g[L.n_groups++] = g;
+            if (g.n_long > 0) blocks += ((g.n_long + 3) / 4 + 7) / 8 * 8;
+            if (g.n_short > 0) sblocks += (g.n_short + (kBlock / G) - 1) / (kBlock / G);
+        }
+        L.blk_start[L.n_groups] = blocks;
+        L.blk_short[L.n_groups] = sblocks;
+        L.n_long_blocks = blocks;
+        if (blocks + sblocks > 0) {
+            ProfScope ps(nm, stream, 0.0);
+            hipLaunchKernelGGL((bwd_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
+            PEA_HIP(hipGetLastError());
+        }
+    }
+    {   // hub merge
         L.n_groups = 0;
         int blocks = 0;
         for (int i = 0; i < n_sel; ++i) {
             const AggGroup &g = base.g[sel[i]];
-            const int n = pass == 0 ? g.n_short : pass == 1 ? g.n_long : g.n_hub;
-            if (n <= 0) continue;
+            if (g.n_hub <= 0) continue;
             L.blk_start[L.n_groups] = blocks;
             L.g[L.n_groups++] = g;
-            blocks += pass == 0 ? (n + (kBlock / G) - 1) / (kBlock / G) : pass == 1 ? ((n + 3) / 4 + 7) / 8 * 8 : (n + 3) / 4;
+            blocks += (g.n_hub + 3) / 4;
         }
         L.blk_start[L.n_groups] = blocks;
-        if (blocks == 0) continue;
-        ProfScope ps(nm, stream, 0.0);
-        if (pass == 0) hipLaunchKernelGGL((bwd_short_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
-        else if (pass == 1) hipLaunchKernelGGL((bwd_long_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
-        else hipLaunchKernelGGL((bwd_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
-        PEA_HIP(hipGetLastError());
+        if (blocks > 0) {
+            ProfScope ps(nm, stream, 0.0);
+            hipLaunchKernelGGL((bwd_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+            PEA_HIP(hipGetLastError());
+        }
     }
     return PEA_OK;
 }
