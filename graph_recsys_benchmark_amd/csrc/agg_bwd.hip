@@ -551,9 +551,18 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const RowMap M, int W4, 
                                                         const float *__restrict__ O, int ldo) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= M.n * W4) return;
-    const int64_t r = M.row(idx / W4);
+    int64_t q;
+    int c;
+    if (M.n * W4 < (int64_t)1 << 31) {   // 32-bit division (the usual case): the 64-bit one costs ~40 instructions per thread
+        const unsigned qi = (unsigned)idx / (unsigned)W4;
+        q = qi;
+        c = (int)((unsigned)idx - qi * (unsigned)W4) * 4;
+    } else {
+        q = idx / W4;
+        c = (int)(idx % W4) * 4;
+    }
+    const int64_t r = M.row(q);
     if (r >= M.N) return;
-    const int c = (int)(idx % W4) * 4;
     float4 g = ld4(G + r * ldg + c);
     const float4 o = ld4(O + r * ldo + c);
     g.x = o.x > 0.f ? g.x : 0.f;

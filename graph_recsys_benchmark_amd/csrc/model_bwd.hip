@@ -135,6 +135,19 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         // rows whose softmax is their self loop alone are skipped by the D pass (alpha = 1, d z = 0): their d a_dst reads 0
         PEA_HIP(hipMemsetAsync(wsf + L.off_dad, 0, (size_t)N * (size_t)L.ld_k * sizeof(float), stream));
     }
+    // relu between the steps (reference models/base.py:138): the output gradient of the channels that continue is masked
+    // in place, one launch per run of groups whose columns are contiguous in dO (a 2-step model's first level: the whole row)
+    if (part_a) {
+        size_t ri = 0;
+        while (ri < L.groups.size()) {
+            const GroupPlan &g0 = L.groups[ri];
+            size_t rj = ri + 1;
+            int W = g0.W;
+            while (!g0.last && rj < L.groups.size() && !L.groups[rj].last && L.groups[rj].out_col == g0.out_col + W) W += L.groups[rj++].W;
+            if (!g0.last) PEA_TRY(launch_relu_mask(own, W, dO + g0.out_col, L.ld_o, O + g0.out_col, L.ld_o, stream));
+            ri = rj;
+        }
+    }
     std::vector<AggGroup> gd, gsrc;
     for (const GroupPlan &g : L.groups) {
         const int rr = m->reverse_of[(size_t)g.rel];
@@ -145,7 +158,6 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         float *G = g.last ? dX + g.out_col : dO + g.out_col;
         const float *Out = g.last ? X + g.out_col : O + g.out_col;
         const int ldg = g.last ? m->ld_x : L.ld_o;
-        if (!g.last && part_a) PEA_TRY(launch_relu_mask(own, g.W, G, ldg, Out, ldg, stream));
         AggGroup a{};
         a.W = g.W;
         a.F = g.F;
