@@ -46,8 +46,10 @@ class GwJob(C.Structure):
 
 class DenseJob(C.Structure):
     _fields_ = [('a', C.c_void_p), ('lda', C.c_int64), ('k', C.c_int), ('w', C.c_void_p), ('ldw', C.c_int64),
-                ('n_out', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64)]
+                ('n_out', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64), ('gate', C.c_void_p), ('ld_gate', C.c_int64)]
 
+
+BWD_PREMASKED = 0x100     # include/peahip.h PEA_BWD_PREMASKED
 
 # every symbol include/peahip.h declares: name -> (restype, argtypes)
 _vp, _i64, _int, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t

@@ -118,7 +118,11 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                     dX[:, u['o_col']:u['o_col'] + u['HF']] = d_stack[:, u['p'], :]
     stream = _lib.current_stream()
 
+    premasked = set()      # levels whose output gradients were written through a gated product (relu mask applied there)
+
     def level_call(level, phase):
+        if level in premasked:
+            phase |= _lib.BWD_PREMASKED
         _lib.check(lib.pea_model_backward_level(engine._h, level, phase, _lib.ptr(engine._ws), engine.workspace_bytes,
                                                 stream))
 
@@ -237,6 +241,10 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             dense_batch([(dT0, w_cat, dx)], rows=own32)                     # dx = dT_0 W_cat: one deep-K job (K = sum HF)
         # weight gradients of the level in one launch pair, input gradients in one launch (dense_bwd.hip)
         if s > 0:
+            # dIn = dT W is the output gradient of the level below BEFORE its relu mask; In (= that level's relu output)
+            # is the mask: applied in the product's epilogue when every job qualifies (k <= 128, more than 16 outputs:
+            # the persistent transform kernel), so that level's own mask pass over the buffer is skipped
+            gated = all(u['HF'] <= 128 and u['in_w'] > 16 for u in units)
             pairs, dense = [], []
             for u in units:
                 li = first[u['p']] + u['s']
@@ -245,13 +253,15 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 dIn = dIn_all[:, u['in_col']:u['in_col'] + u['in_w']]
                 if kind == 'gat':
                     pairs.append((dTu, In))                                     # [HF, in]
-                    dense.append((dTu, layer_params[li][0], dIn))               # dT @ W
+                    dense.append((dTu, layer_params[li][0], dIn) + ((In,) if gated else ()))               # dT @ W
                 else:
                     pairs.append((In, dTu))                                     # [in, F]
-                    dense.append((dTu, layer_params[li][0].t().contiguous(), dIn))
+                    dense.append((dTu, layer_params[li][0].t().contiguous(), dIn) + ((In,) if gated else ()))
             dWs = grad_weight(pairs, shard=shard3)
             to_reduce.extend(dWs)
             dense_batch(dense, rows=own32)
+            if gated:
+                premasked.add(s - 1)
         for q, u in enumerate(units):
             li = first[u['p']] + u['s']
             if kind == 'gat':

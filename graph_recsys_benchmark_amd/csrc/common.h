@@ -252,6 +252,11 @@ struct GemmSegment {   // output columns [c0, c1) of the job go to dst[row*ld + 
     float *dst;
     int ld;
     int relu;
+    // optional gate (same column mapping as dst): out = gate[row*ld_gate + (c - c0)] > 0 ? value : 0 -- the relu mask of
+    // the layer whose output gradient this job writes (the backward's dIn = dT W), applied in the epilogue instead of by
+    // a separate pass over the buffer.  Persistent kernel only, jobs of at most 64 output columns per item (see gemm.hip).
+    const float *gate;
+    int ld_gate;
 };
 constexpr int kMaxSegments = 4;
 struct GemmJob {

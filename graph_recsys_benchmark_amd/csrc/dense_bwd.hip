@@ -308,6 +308,10 @@ extern "C" int pea_dense_batch_rows(int64_t n_rows, const int32_t *rows, int n_j
         J.seg[0].dst = S.out;
         J.seg[0].ld = (int)S.ldo;
         J.seg[0].relu = 0;
+        PEA_REQUIRE(S.gate == nullptr || (S.ld_gate >= S.n_out && S.k <= 128), PEA_ERR_ARG,
+                    "dense_batch: job %d: a gate needs a row stride covering the columns and k <= 128", q);
+        J.seg[0].gate = S.gate;
+        J.seg[0].ld_gate = (int)S.ld_gate;
         jobs[(size_t)q] = J;
     }
     return launch_gemm_batch(jobs.data(), n_jobs, rows, n_rows, (hipStream_t)stream);

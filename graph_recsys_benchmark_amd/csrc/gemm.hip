@@ -368,6 +368,31 @@ __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(cons
         const float *bias_img = g_lds + Pa.lds_off[j] + 2 * KH * ld + r;
         const int nct = (n_out + 31) / 32;
         const int ct_end = min(nct, (grp + 1) * Pa.col_group);
+        // gated jobs (col_group <= 2 for them): the gate values of this lane's 16 rows x 2 column tiles are fetched here,
+        // before the column loop, which must not issue a global load (see the bias row of the image)
+        float gv[2][16];
+        const bool gated = S[0].gate != nullptr;   // wave-uniform; a gated job has the gate on every segment
+        if (gated) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int c = (grp * Pa.col_group + t) * 32 + r;
+                const float *gp = nullptr;
+                int ldg = 0;
+#pragma unroll
+                for (int sg = 0; sg < kMaxSegments; ++sg) {
+                    const bool in = c >= S[sg].c0 && c < S[sg].c1;
+                    gp = in ? S[sg].gate + (c - S[sg].c0) : gp;
+                    ldg = in ? S[sg].ld_gate : ldg;
+                }
+                const bool col_ok = gp != nullptr && c < n_out && grp * Pa.col_group + t < ct_end;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t rr = (LISTED || row0 + 32 > jn) ? (int64_t)orow[reg] : row0 + 4 * h + (reg & 3) + 8 * (reg >> 2);
+                    const bool ok = col_ok && ((valid >> reg) & 1u);
+                    gv[t][reg] = ok ? gp[(ok ? rr : 0) * ldg] : 1.f;
+                }
+            }
+        }
         for (int ct = grp * Pa.col_group; ct < ct_end; ++ct) {
             const int col0 = ct * 32, c = col0 + r;
             const float bias = bias_img[col0];
@@ -406,6 +431,11 @@ __global__ __launch_bounds__(KH > 32 ? 512 : 1024) void gemm_persist_kernel(cons
             for (int reg = 0; reg < 16; ++reg) {
                 const float t = acc[reg] + bias;
                 v[reg] = relu ? fmaxf(t, 0.f) : t;
+            }
+            if (gated) {
+                const int t = ct - grp * Pa.col_group;   // 0 or 1
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) v[reg] = (t == 0 ? gv[0][reg] : gv[1][reg]) > 0.f ? v[reg] : 0.f;
             }
             if (LISTED) {
 #pragma unroll
@@ -580,7 +610,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmBatch Bt, co
 
 // a job qualifies when its output is at most 16 columns wide, k fits 128 and every segment can take float4 stores
 static bool skinny_ok(const GemmJob &J) {
-    if (J.no_narrow || J.n_out > 16 || J.K1 + J.K2 > 128 || J.ldb < J.n_out) return false;
+    if (J.no_narrow || J.seg[0].gate || J.n_out > 16 || J.K1 + J.K2 > 128 || J.ldb < J.n_out) return false;
     for (int sg = 0; sg < J.n_seg; ++sg) {
         const GemmSegment &S = J.seg[sg];
         if (S.c0 % 4 || S.c1 % 4 || S.ld % 4 || (reinterpret_cast<uintptr_t>(S.dst) & 15)) return false;
@@ -723,6 +753,8 @@ template <int KH>
 int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double bytes, hipStream_t stream) {
     PersistArgs Pa;
     Pa.col_group = kColGroup;
+    for (int j = 0; j < Bt.n; ++j)
+        if (Bt.j[j].seg[0].gate) Pa.col_group = 2;   // gated epilogues hold the gate values of two column tiles
     int off = 0, items = 0;
     bool listed = rows != nullptr;
     for (int j = 0; j < Bt.n; ++j) {
@@ -734,7 +766,7 @@ int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double 
         Pa.lds_off[j] = off;
         off += (2 * KH + 1) * Pa.lds_ld[j];
         Pa.item_start[j] = items;
-        items += n_tiles * ((nct + kColGroup - 1) / kColGroup);
+        items += n_tiles * ((nct + Pa.col_group - 1) / Pa.col_group);
     }
     Pa.item_start[Bt.n] = items;
     Pa.n_items = items;
@@ -759,6 +791,15 @@ int launch_persist(const GemmBatch &Bt, const int *rows, int64_t n_rows, double 
 int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, int64_t n_rows, hipStream_t stream) {
     if (n_jobs_in <= 0) return PEA_OK;
     std::vector<GemmJob> jobs;
+    for (int i = 0; i < n_jobs_in; ++i) {   // a gated epilogue exists in the persistent kernel only (k <= 128)
+        bool any = false, all = true;
+        for (int sg = 0; sg < jobs_in[i].n_seg; ++sg) {
+            any = any || jobs_in[i].seg[sg].gate != nullptr;
+            all = all && jobs_in[i].seg[sg].gate != nullptr;
+        }
+        PEA_REQUIRE(!any || (all && jobs_in[i].K1 + jobs_in[i].K2 <= 128), PEA_ERR_ARG,
+                    "gemm: a gated job needs the gate on every segment and k <= 128");
+    }
     // narrow outputs first: one launch per k class
     for (int kq : {2, 4, 8}) {
         GemmBatch Bt;
@@ -810,6 +851,7 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                 if (a1 <= a0) continue;
                 GemmSegment S = J.seg[sg];
                 S.dst = J.seg[sg].dst + (a0 - J.seg[sg].c0);
+                if (S.gate) S.gate = J.seg[sg].gate + (a0 - J.seg[sg].c0);
                 S.c0 = a0 - c0;
                 S.c1 = a1 - c0;
                 C.seg[C.n_seg++] = S;

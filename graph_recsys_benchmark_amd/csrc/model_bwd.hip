@@ -75,6 +75,8 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
                                         void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PEA_REQUIRE(m && workspace && m->backward, PEA_ERR_ARG, "backward: model without enable_backward");
+    const bool premasked = (phase & PEA_BWD_PREMASKED) != 0;   // the producer of this level's output gradients applied the relu mask
+    phase &= ~PEA_BWD_PREMASKED;
     PEA_REQUIRE(level >= 0 && level < (int)m->levels.size() && phase >= 0 && phase <= 2, PEA_ERR_ARG, "backward: level %d phase %d", level, phase);
     PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(m), PEA_ERR_NOMEM, "backward: workspace too small");
     float *wsf = aligned_ws(workspace);
@@ -137,7 +139,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
     }
     // relu between the steps (reference models/base.py:138): the output gradient of the channels that continue is masked
     // in place, one launch per run of groups whose columns are contiguous in dO (a 2-step model's first level: the whole row)
-    if (part_a) {
+    if (part_a && !premasked) {
         size_t ri = 0;
         while (ri < L.groups.size()) {
             const GroupPlan &g0 = L.groups[ri];

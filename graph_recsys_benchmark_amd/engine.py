@@ -332,21 +332,30 @@ def grad_weight(pairs, shard=None):
 def dense_batch(triples_, rows=None):
     """out_q = a_q @ w_q for (a_q [N, k], w_q [k, n_out], out_q [N, n_out] view) in triples_: one launch (the input
     gradients dIn = dT W of one level); k, n_out and a's row stride must be multiples of 4.  rows (int32 device tensor):
-    only those rows are computed (the rows a rank owns in a sharded training step)."""
+    only those rows are computed (the rows a rank owns in a sharded training step).  A fourth element gate_q [N, n_out]
+    (k <= 128) zeroes the outputs where gate_q <= 0: the relu mask of the layer below, applied in the epilogue."""
     lib = _lib.require_device()
     if not triples_:
         return
     n = triples_[0][0].shape[0]
     jobs = (_lib.DenseJob * len(triples_))()
     keep = []
-    for q, (a, w, out) in enumerate(triples_):
+    for q, item in enumerate(triples_):
+        a, w, out = item[:3]
+        gate = item[3] if len(item) > 3 else None
         a, out = _rows2d(a), _rows2d(out)
         w = _rows2d(w if w.stride(1) == 1 else w.contiguous())
         keep.append(w)
         if a.shape != (n, w.shape[0]) or out.shape != (n, w.shape[1]):
             raise ValueError('dense_batch: shapes %s @ %s -> %s' % (tuple(a.shape), tuple(w.shape), tuple(out.shape)))
+        g_ptr, g_ld = None, 0
+        if gate is not None:
+            gate = _rows2d(gate)
+            if gate.shape != out.shape:
+                raise ValueError('dense_batch: gate %s for output %s' % (tuple(gate.shape), tuple(out.shape)))
+            g_ptr, g_ld = gate.data_ptr(), gate.stride(0)
         jobs[q] = _lib.DenseJob(a.data_ptr(), a.stride(0), w.shape[0], w.data_ptr(), w.stride(0), w.shape[1],
-                                out.data_ptr(), out.stride(0))
+                                out.data_ptr(), out.stride(0), g_ptr, g_ld)
     if rows is not None:
         _lib.check(lib.pea_dense_batch_rows(rows.numel(), _lib.ptr(rows), len(triples_), jobs, _lib.current_stream()))
     else:

@@ -172,7 +172,10 @@ int pea_model_set_active_rows(pea_model *model, const unsigned char *row_active)
  *                   jobs over the same n_rows: the weight gradients dW = dT^T In (GAT lin, SAGE lin_rel / lin_root) or
  *                   In^T dT (GCN).  Row parts are reduced in a fixed order: bitwise reproducible, no atomics.
  * pea_dense_batch:  out[n][c] = sum_k a[n*lda + k] * w[k*ldw + c]   (k and n_out multiples of 4): the input gradients
- *                   dIn = dT W of one level, all channels in one launch.                                              */
+ *                   dIn = dT W of one level, all channels in one launch.
+ * pea_model_backward_level: phase | PEA_BWD_PREMASKED = the level's output gradients already carry the relu mask (its
+ *                   producer was a gated pea_dense_batch): the level's own relu-mask pass is skipped.                 */
+#define PEA_BWD_PREMASKED 0x100
 typedef struct pea_gw_job {
     const float *a; int64_t lda; int ma;
     const float *b; int64_t ldb; int nb;
@@ -182,6 +185,9 @@ typedef struct pea_dense_job {
     const float *a; int64_t lda; int k;
     const float *w; int64_t ldw; int n_out;
     float *out; int64_t ldo;
+    /* optional relu gate (NULL: none): out[n][c] = gate[n*ld_gate + c] > 0 ? (a w)[n][c] : 0 -- the mask `F.relu` of the
+     * layer below puts on its output gradient (models/base.py:138), applied in the product's epilogue; k <= 128 */
+    const float *gate; int64_t ld_gate;
 } pea_dense_job;
 size_t pea_grad_weight_workspace_bytes(void);
 int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes,
