@@ -400,15 +400,16 @@ class PEALossFunction(torch.autograd.Function):
         with torch.no_grad():
             if mask is not None:
                 _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, _lib.ptr(mask)))
+            # the conv stack's backward is linear in the batch's gradient rows: the upstream gradient scales them once
+            # ([3B, P * R]) instead of every one of the ~80 parameter gradients afterwards
             try:
-                dx, grads = backward_conv_stack(ctx.engine, None, x, layer_params, ctx.ids, compact=(ctx.ids_b, ctx.grad_rows))
+                dx, grads = backward_conv_stack(ctx.engine, None, x, layer_params, ctx.ids, compact=(ctx.ids_b, ctx.grad_rows * g))
             finally:
                 if mask is not None:
                     _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, None))
-            # everything above is linear in the upstream gradient: scale once at the end
             out = []
             for lp, gl in zip(layer_params, grads):
                 for t, gt in zip(lp, gl):
-                    out.append(None if t is None else gt.reshape(t.shape) * g)
+                    out.append(None if t is None else gt.reshape(t.shape))
             head = tuple(None if t is None else t * g for t in ctx.head)
-            return (None, dx * g, None, None, None) + head + tuple(out)
+            return (None, dx, None, None, None) + head + tuple(out)

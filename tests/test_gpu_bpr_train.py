@@ -78,6 +78,11 @@ def test_training_loss_of_a_model_uses_the_hip_head_and_matches_the_torch_head(a
         engine.bpr_train_raw = orig_raw
     assert calls, 'the training loss did not go through csrc/bpr_train.hip'
     got = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    model.zero_grad()
+    (0.5 * model.loss(batch)).backward()        # a non-unit upstream gradient scales every gradient (exactly: a power of two)
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            assert torch.equal(v.grad, 0.5 * got[k]), k
     orig = engine.bpr_train_supported
     engine.bpr_train_supported = lambda *_: False     # the torch-op head (kept for repr_dim > 32)
     try:
