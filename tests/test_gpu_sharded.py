@@ -88,6 +88,51 @@ def test_sharded_narrow_layers_are_bit_exact(kind, hidden, repr_dim):
     mp.spawn(_worker, args=(2, _free_port(), kind, 1, hidden, repr_dim), nprocs=2, join=True)
 
 
+def _twostep_worker(rank, world, port, kind, emb, hidden):
+    """Configurations the two-step inference schedule takes (every channel 2 steps, emb / hidden 64 or 128: csrc/mlp2.hip
+    on the rank's own rows, first-layer aggregation of the replicated x): sharded == single GPU, bit for bit."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from helpers import build_model, random_hin, random_state_dict
+        torch.cuda.set_device(0)
+        n, blocks, rel = random_hin(23, n_user=2500, n_item=800, n_attr=40, e_u2i=30000, e_attr=2000)
+        u2i, a2i = rel['u2i'], rel['a2i']
+        flip = lambda e: np.ascontiguousarray(e[::-1])
+        edges = [[u2i, flip(u2i)], [flip(u2i), u2i], [a2i, flip(u2i)], [a2i, flip(u2i)], [flip(a2i), a2i]]
+        model = build_model(kind, n, edges, [2] * len(edges), emb, hidden, 16)
+        model.load_state_dict(random_state_dict(model, 11, scale=0.2))
+        model.eval()
+        from test_gpu_edge_cases import _kernel_names_of_one_forward
+        assert 'mlp2_fused' in _kernel_names_of_one_forward(model)      # this configuration does take the two-step schedule
+        rng = np.random.default_rng(6)
+        (u0, u1), (i0, i1) = blocks['u'], blocks['i']
+        batch = torch.from_numpy(np.stack([rng.integers(u0, u1, 200), rng.integers(i0, i1, 200),
+                                           rng.integers(i0, i1, 200)], axis=1).astype(np.int64)).cuda()
+        with torch.no_grad():
+            ref, ref_stack = model.forward(return_stack=True)
+            model.train()
+            ref_loss = model.loss(batch)
+            model.eval()
+            model.shard(rank, world, tile=64)
+            got, got_stack = model.forward(return_stack=True)
+            model.train()
+            got_loss = model.loss(batch)
+            model.eval()
+        assert 'mlp2_fused' in _kernel_names_of_one_forward(model)      # ... and still does on a rank of a sharded plan
+        assert torch.equal(got, ref), 'rank %d: fused rows differ (max %g)' % (rank, (got - ref).abs().max())
+        assert torch.equal(got_stack, ref_stack)
+        assert torch.equal(got_loss, ref_loss)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind,emb,hidden,world', [('gat', 64, 64, 2), ('gcn', 64, 128, 3), ('sage', 64, 64, 2),
+                                                   ('sage', 128, 64, 3), ('gat', 128, 128, 5)])
+def test_sharded_two_step_schedule_is_bit_exact(kind, emb, hidden, world):
+    mp.spawn(_twostep_worker, args=(world, _free_port(), kind, emb, hidden), nprocs=world, join=True)
+
+
 def _train_worker(rank, world, port, kind, heads):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
