@@ -288,6 +288,91 @@ __global__ __launch_bounds__(256) void gemm_deep_kernel(const GemmBatch Bt, cons
     }
 }
 
+// Deep k with a B that fits the LDS whole (K x 32 NCT floats <= 150 KB: the 25m model's dx = dT_0 W_cat is 576 x 64 =
+// 147 KB): every workgroup copies B once, then its 16 waves walk 32-row tiles with NO barrier, like the persistent kernel
+// below, but over k chunks of 64.  Same k order
+// per output as gemm_deep_kernel.
+// lean A fragment load for jobs with one input block and no edge-less-row substitution (the backward's products): no
+// temporaries beyond the fragment itself
+template <int KH>
+__device__ __forceinline__ void load_a_plain(const GemmJob &J, int64_t srow, bool rv, int kbase, float (&a)[KH]) {
+    const float *p = J.A1 + srow * J.lda1;
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+        const int k = kbase + q * 4;
+        const bool keep = rv && k < J.K1;
+        const float4 t = ld4(p + (k < J.K1 ? k : 0));
+        a[q * 4 + 0] = keep ? t.x : 0.f;
+        a[q * 4 + 1] = keep ? t.y : 0.f;
+        a[q * 4 + 2] = keep ? t.z : 0.f;
+        a[q * 4 + 3] = keep ? t.w : 0.f;
+    }
+}
+
+template <int NCT>
+__global__ __launch_bounds__(1024) void gemm_deep_resident_kernel(const GemmBatch Bt, const int *__restrict__ rows, int64_t n_rows) {
+    constexpr int KH = 32, W = 32 * NCT, NW = 16;   // 64-deep k chunks: 112 registers per lane, 16 waves per CU
+    const GemmJob &J = Bt.j[blockIdx.y];
+    if (J.rows) {
+        rows = J.rows;
+        n_rows = J.n_rows;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const int K = J.K1 + J.K2;
+    const int nkc = (K + 2 * KH - 1) / (2 * KH);
+    for (int idx = tid; idx < K * (W / 4); idx += 1024) {   // the whole k-major B: K rows (a partial last chunk re-reads row K - 1
+        const int k = idx / (W / 4), c = (idx % (W / 4)) * 4;   // against A values that are zero there)
+        *reinterpret_cast<float4 *>(g_lds + (size_t)k * W + c) = c < J.ldb ? ld4(J.B + (size_t)k * J.ldb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
+        const int64_t row0 = tile * 32, grow = row0 + r;
+        const bool rv = grow < n_rows;
+        const int64_t srow = rv ? (rows ? (int64_t)rows[grow] : grow) : 0;
+        int orow[16];
+        const unsigned valid = load_orow(rows, row0, h, n_rows, orow);
+        float a[KH];   // no second fragment buffer: 16 waves per CU cover the load latency, a 128-register budget does not fit one
+        f32x16 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+        for (int kc = 0; kc < nkc; ++kc) {
+            load_a_plain<KH>(J, srow, rv, kc * 2 * KH + h * KH, a);
+            const float *bs = g_lds + ((size_t)kc * 2 * KH + h * KH) * W + r;
+            const bool last_partial = (kc + 1) * 2 * KH > K;            // wave-uniform
+            const int kbase = kc * 2 * KH + h * KH;                     // first image row of this lane half's 64
+            // B operands in batches of 8 LDS reads per column tile, fenced: left alone, the scheduler hoists all 64 * NCT
+            // reads of the chunk ahead of the MFMAs and spills
+#pragma unroll
+            for (int g = 0; g < KH / 8; ++g) {
+                float bb[NCT][8];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int kl = 8 * g + u;   // row kc * 128 + h * 64 + kl of the image, clamped in a partial last chunk
+                        bb[ct][u] = last_partial ? g_lds[(size_t)min(kbase + kl, K - 1) * W + r + 32 * ct] : bs[kl * W + 32 * ct];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * g + u], bb[ct][u], acc[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int c = 32 * ct + r;
+            const OutCol o = find_out(J, c);
+            const float bias = (J.bias && c < J.n_out) ? J.bias[c] : 0.f;
+            store_tile(acc[ct], o, bias, rows != nullptr, orow, valid, row0, h);
+        }
+    }
+}
+
 // Persistent variant (the default): every workgroup first copies the WHOLE k-major B of all its jobs into LDS
 // (the 9 first-layer transforms of the MovieLens model are one 64 x 596 block = 149 KiB of the CU's 160 KiB), then its
 // 16 waves walk (job, 32-row tile, column group) items with no barrier at all: A fragment from global, B fragment
@@ -884,7 +969,29 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                     int max_out = 0;
                     for (int q = 0; q < Bt.n; ++q) max_out = std::max(max_out, Bt.j[q].n_out);
                     const char *env = getenv("PEA_DEEP_STAGED");   // A/B switch: the per-column-tile staged kernel
-                    if (max_out <= 128 && !(env && atoi(env) != 0)) {
+                    int max_k = 0;
+                    for (int q = 0; q < Bt.n; ++q) max_k = std::max(max_k, Bt.j[q].K1 + Bt.j[q].K2);
+                    const int nct_r = max_out <= 32 ? 1 : max_out <= 64 ? 2 : 4;
+                    const size_t lds_res = (size_t)max_k * 32 * nct_r * sizeof(float);
+                    bool plain = true;   // one input block, no edge-less-row substitution: what the resident kernel's loader takes
+                    for (int q = 0; q < Bt.n; ++q) plain = plain && Bt.j[q].K2 == 0 && Bt.j[q].a1_mask == nullptr;
+                    if (plain && max_out <= 64 && lds_res <= kLdsBudget && !(env && atoi(env) != 0)) {   // (4 column tiles would spill)
+                        // B resident in LDS, no barriers: persistent workgroups of 8 waves
+                        static bool attr_res = false;
+                        if (!attr_res) {
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_deep_resident_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_deep_resident_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+                            attr_res = true;
+                        }
+                        hipDeviceProp_t prop;
+                        int dev = 0;
+                        static int n_cu_deep = 0;
+                        if (!n_cu_deep && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_deep = prop.multiProcessorCount;
+                        const int64_t tiles = (max_rows + 31) / 32;
+                        dim3 grid_r((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu_deep > 0 ? n_cu_deep : 256, (tiles + 15) / 16)), (unsigned)Bt.n);
+                        if (nct_r == 1) hipLaunchKernelGGL(gemm_deep_resident_kernel<1>, grid_r, dim3(1024), lds_res, stream, Bt, rows, n_rows);
+                        else hipLaunchKernelGGL(gemm_deep_resident_kernel<2>, grid_r, dim3(1024), lds_res, stream, Bt, rows, n_rows);
+                    } else if (max_out <= 128 && !(env && atoi(env) != 0)) {
                         const int nct = max_out <= 32 ? 1 : max_out <= 64 ? 2 : 4;
                         const size_t lds_deep = (size_t)2 * 128 * 32 * nct * sizeof(float);
                         static bool attr_set = false;
