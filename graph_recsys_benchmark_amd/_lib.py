@@ -105,7 +105,7 @@ SIGNATURES = {
     'pea_bpr_train_supported': (_int, [_int, _int]),
     'pea_bpr_train': (_int, [_i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     'pea_rows_scatter_sum_workspace_bytes': (C.c_size_t, [_i64]),
-    'pea_rows_scatter_sum': (_int, [_i64, _vp, _vp, _i64, _int, _int, C.POINTER(_int), _vp, _i64, _vp, C.c_size_t, _vp]),
+    'pea_rows_scatter_sum': (_int, [_i64, _vp, _vp, _i64, _int, _int, C.POINTER(_int), _vp, _i64, _i64, _vp, C.c_size_t, _vp]),
     'pea_rows_pack': (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp, _i64, _vp]),
     'pea_rows_unpack': (_int, [_vp, _i64, _vp, _int, _vp, _i64, _vp, _i64, _int, _vp]),
     'pea_rows_select_owned': (_int, [_vp, _i64, _int, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),

@@ -270,7 +270,7 @@ constexpr int kBuckets = 2048;
 // scratch slots, never the result), then every key finds its rank inside its bucket by counting the smaller keys there
 // (buckets hold a handful of keys; a node named 500 times makes 500 threads read 500 keys each).  Output: the keys ordered
 // by (bucket, id, position): the positions of one node are one run, in position order.  Keys of ids < 0 go last (~0).
-__global__ __launch_bounds__(kSortThreads) void sort_ids_kernel(int n, const int64_t *__restrict__ ids,
+__global__ __launch_bounds__(kSortThreads) void sort_ids_kernel(int n, int64_t num_rows, const int64_t *__restrict__ ids,
                                                                 unsigned long long *__restrict__ sorted) {
     unsigned long long *tmp = reinterpret_cast<unsigned long long *>(tsm);     // [n] keys in bucket order, unordered inside
     __shared__ int start[kBuckets + 1], cursor[kBuckets];
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_ids_kernel(int n, const int
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kSortThreads) {
         const int64_t id = ids[i];
-        if (id >= 0) atomicAdd(&cursor[(int)(id % kBuckets)], 1);
+        if (id >= 0 && id < num_rows) atomicAdd(&cursor[(int)(id % kBuckets)], 1);   // ids outside the table are skipped like negative ones
     }
     __syncthreads();
     {   // exclusive prefix sum of the 2048 counts: 2 per thread, wave scan, then the 16 wave totals
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_ids_kernel(int n, const int
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kSortThreads) {
         const int64_t id = ids[i];
-        if (id < 0) continue;
+        if (id < 0 || id >= num_rows) continue;
         const int b = (int)(id % kBuckets);
         tmp[start[b] + atomicAdd(&cursor[b], 1)] = ((unsigned long long)id << 32) | (unsigned)i;
     }
@@ -380,14 +380,15 @@ using namespace pea;
 extern "C" size_t pea_rows_scatter_sum_workspace_bytes(int64_t n) { return n < 0 ? 0 : (size_t)n * 8 + 256; }
 
 extern "C" int pea_rows_scatter_sum(int64_t n, const int64_t *ids, const float *src, int64_t ld_src, int P, int R,
-                                    const int *col_of_channel_host, float *dst, int64_t ld_dst, void *workspace,
-                                    size_t workspace_bytes, void *stream_) {
+                                    const int *col_of_channel_host, float *dst, int64_t ld_dst, int64_t num_rows,
+                                    void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PEA_REQUIRE(n >= 0 && n <= kSortMax, PEA_ERR_ARG, "rows_scatter_sum: %lld positions (the batch is sorted in LDS: <= %d)",
                 (long long)n, kSortMax);
     PEA_REQUIRE(P > 0 && P <= kMaxChannels && R > 0 && R % 4 == 0 && P * R <= 1024, PEA_ERR_ARG,
                 "rows_scatter_sum: P=%d R=%d (R a multiple of 4, P * R <= 1024)", P, R);
-    PEA_REQUIRE(ids && src && dst && col_of_channel_host && ld_src >= (int64_t)P * R && ld_src % 4 == 0 && ld_dst % 4 == 0,
+    PEA_REQUIRE(ids && src && dst && col_of_channel_host && ld_src >= (int64_t)P * R && ld_src % 4 == 0 && ld_dst % 4 == 0 &&
+                    num_rows >= 0 && num_rows < ((int64_t)1 << 31),
                 PEA_ERR_ARG, "rows_scatter_sum: bad argument");
     PEA_REQUIRE(workspace && workspace_bytes >= pea_rows_scatter_sum_workspace_bytes(n), PEA_ERR_NOMEM, "rows_scatter_sum: workspace too small");
     if (n == 0) return PEA_OK;
@@ -404,7 +405,7 @@ extern "C" int pea_rows_scatter_sum(int64_t n, const int64_t *ids, const float *
         attr_set = true;
     }
     ProfScope ps("scatter_sum", stream, (double)n * P * R * 8.0);
-    hipLaunchKernelGGL(sort_ids_kernel, dim3(1), dim3(kSortThreads), (size_t)n * 8, stream, (int)n, ids, sorted);
+    hipLaunchKernelGGL(sort_ids_kernel, dim3(1), dim3(kSortThreads), (size_t)n * 8, stream, (int)n, num_rows, ids, sorted);
     PEA_HIP(hipGetLastError());
     const int blocks = (int)((n + 3) / 4);
     if (P * R > 256) {

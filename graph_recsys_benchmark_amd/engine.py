@@ -544,7 +544,7 @@ def rows_scatter_sum(ids, src, num_channels, repr_dim, col_of_channel, dst):
     ws_bytes = int(lib.pea_rows_scatter_sum_workspace_bytes(ids.numel()))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
     _lib.check(lib.pea_rows_scatter_sum(ids.numel(), _lib.ptr(ids), _lib.ptr(src), src.stride(0), int(num_channels), int(repr_dim),
-                                        cols, _lib.ptr(dst), dst.stride(0), _lib.ptr(ws), ws_bytes, _lib.current_stream()))
+                                        cols, _lib.ptr(dst), dst.stride(0), dst.shape[0], _lib.ptr(ws), ws_bytes, _lib.current_stream()))
 
 
 ROWS_SCATTER_MAX = 16384      # positions pea_rows_scatter_sum sorts in LDS (a BPR batch of up to 5461 triples)

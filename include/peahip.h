@@ -353,7 +353,7 @@ int pea_entity_reg(int64_t B, int emb_dim, int64_t num_nodes, const float *x, in
  * pea_rows_scatter_sum: dst[id, col_of_channel[p] + c] = sum over the positions k with ids[k] == id of src[k, p*R + c],
  * added in increasing k (the index backward of rows = stack[ids]: the batch's gradient rows into the node-indexed
  * output-gradient buffer: the batch's (id, position) keys are sorted in LDS by one workgroup, then one wave per node adds
- * its rows in position order; ids < 0 are skipped; n <= 16384, P*R <= 1024).
+ * its rows in position order; ids < 0 or >= num_rows (the rows of dst) are skipped; n <= 16384, P*R <= 1024).
  * ---------------------------------------------------------------------------------------------- */
 size_t pea_bpr_train_workspace_bytes(int64_t B);
 int pea_bpr_train_supported(int P, int R);
@@ -362,7 +362,7 @@ int pea_bpr_train(int64_t B, int P, int R, const float *rows, int64_t ld_rows, c
                   float *dhx, float *zx, float *dsc, void *workspace, size_t workspace_bytes, void *stream);
 size_t pea_rows_scatter_sum_workspace_bytes(int64_t n);
 int pea_rows_scatter_sum(int64_t n, const int64_t *ids, const float *src, int64_t ld_src, int P, int R,
-                         const int *col_of_channel_host, float *dst, int64_t ld_dst, void *workspace,
+                         const int *col_of_channel_host, float *dst, int64_t ld_dst, int64_t num_rows, void *workspace,
                          size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

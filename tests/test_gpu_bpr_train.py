@@ -111,6 +111,7 @@ def test_rows_scatter_sum_accumulates_duplicates_in_position_order():
     for n, p, r, nodes in ((1000, 9, 16, 50), (4099, 3, 8, 4000), (1, 1, 4, 3), (12288, 9, 16, 6000), (700, 20, 16, 9), (16384, 2, 4, 100)):
         ids = rng.integers(0, nodes, size=n).astype(np.int64)
         ids[rng.random(n) < 0.1] = -1
+        ids[rng.random(n) < 0.03] = nodes + 3                 # outside the table: skipped like the negative ones
         if n > 10:
             ids[:7] = ids[7]                                     # a run of duplicates at the front
         src = rng.standard_normal((n, p * r)).astype(np.float32)
@@ -119,7 +120,7 @@ def test_rows_scatter_sum_accumulates_duplicates_in_position_order():
         ld = p * r + 4
         want = np.full((nodes, ld), 7.0, dtype=np.float32)      # rows / columns nobody writes keep their value
         want64 = want.astype(np.float64)
-        for i in np.unique(ids[ids >= 0]):
+        for i in np.unique(ids[(ids >= 0) & (ids < nodes)]):
             pos = np.nonzero(ids == i)[0]
             acc = src[pos[0]].copy()
             for q in pos[1:]:
