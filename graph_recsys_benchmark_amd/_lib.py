@@ -44,6 +44,11 @@ class GwJob(C.Structure):
                 ('nb', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64)]
 
 
+class XchgJob(C.Structure):
+    _fields_ = [('table', C.c_void_p), ('ld', C.c_int64), ('col', C.c_int), ('width', C.c_int), ('nodes', C.c_void_p),
+                ('slots', C.c_void_p), ('n', C.c_int64), ('buf_off', C.c_int64), ('slots_per_rank', C.c_int)]
+
+
 class DenseJob(C.Structure):
     _fields_ = [('a', C.c_void_p), ('lda', C.c_int64), ('k', C.c_int), ('w', C.c_void_p), ('ldw', C.c_int64),
                 ('n_out', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64), ('gate', C.c_void_p), ('ld_gate', C.c_int64)]
@@ -108,6 +113,8 @@ SIGNATURES = {
     'pea_rows_scatter_sum': (_int, [_i64, _vp, _vp, _i64, _int, _int, C.POINTER(_int), _vp, _i64, _i64, _vp, C.c_size_t, _vp]),
     'pea_rows_pack': (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp, _i64, _vp]),
     'pea_rows_unpack': (_int, [_vp, _i64, _vp, _int, _vp, _i64, _vp, _i64, _int, _vp]),
+    'pea_rows_pack_batch': (_int, [_int, C.POINTER(XchgJob), _vp, _vp]),
+    'pea_rows_unpack_batch': (_int, [_int, C.POINTER(XchgJob), _vp, _i64, _vp]),
     'pea_rows_select_owned': (_int, [_vp, _i64, _int, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),
     'pea_rank_eval': (_int, [_i64, _int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

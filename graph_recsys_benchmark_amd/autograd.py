@@ -215,16 +215,22 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 else:
                     runs.append(dict(rel=u['rel'], last=u['last'], col=u['o_col'], w=u['HF'], a_k=a_k, heads=u['heads']))
                 a_k += u['heads']
+            # rows every rank owns are complete rows: the batch's rows of the last level travel whole (one all-reduce per
+            # buffer instead of one per run of channels), the other levels' runs in one batched exchange
+            batch_items, ids_done = [], False
             for r in runs:
                 G = dX if r['last'] else dO
                 if r['last'] and active_ids is not None:       # only the batch's rows carry a gradient at the last layer
-                    shard.fill_in_ids(G, r['col'], r['w'], active_ids)
-                    if side is not None:
-                        shard.fill_in_ids(side, 4 * r['a_k'], 4 * r['heads'], active_ids)
+                    if not ids_done:
+                        shard.fill_in_ids(dX, 0, dX.shape[1], active_ids)
+                        if side is not None:
+                            shard.fill_in_ids(side, 0, side.shape[1], active_ids)
+                        ids_done = True
                 else:
-                    shard.fill_in_rows(G, r['col'], r['w'], rev_layout(r['rel']))
+                    batch_items.append((G, r['col'], r['w'], rev_layout(r['rel'])))
                     if side is not None:
-                        shard.fill_in_rows(side, 4 * r['a_k'], 4 * r['heads'], rev_layout(r['rel']))
+                        batch_items.append((side, 4 * r['a_k'], 4 * r['heads'], rev_layout(r['rel'])))
+            shard.fill_in_rows_batch(batch_items)
             level_call(s, 2)
         if s == 0:
             # every first-layer channel reads x: one GEMM for all weight gradients, one for dx

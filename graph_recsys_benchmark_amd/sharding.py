@@ -219,6 +219,44 @@ class ShardLayout:
             else:
                 table[layout.other_nodes, col:col + width] = buf[layout.other_slots]
 
+    def fill_in_rows_batch(self, items, group=None):
+        """fill_in_rows for a list of (table, col, width, layout) with ONE pack launch, ONE all-gather and ONE unpack launch
+        (pea_rows_pack_batch / _unpack_batch on a staging buffer whose rank block holds every item's rows one after the
+        other): a sharded backward level fills in all its gradient buffers at once instead of one exchange per relation
+        and buffer.  CPU tensors (gloo rehearsal) take the per-item path."""
+        items = [it for it in items if it[3].slots_per_rank > 0]
+        if self.world == 1 or not items:
+            return
+        hip = all(t.is_cuda and t.dtype == torch.float32 and w % 4 == 0 and c % 4 == 0 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+                  for t, c, w, _ in items)
+        if not hip or len(items) == 1:
+            for t, c, w, lay in items:
+                self.fill_in_rows(t, c, w, lay, group)
+            return
+        lib = _hip()
+        block = sum(lay.slots_per_rank * w for _, _, w, lay in items)          # floats per rank
+        dev = items[0][0].device
+        key = (str(dev), self.world * block)
+        stage = self._stage.get(key) if hasattr(self, '_stage') else None
+        if stage is None:
+            if not hasattr(self, '_stage'):
+                self._stage = {}
+            stage = self._stage[key] = torch.empty((self.world, block), dtype=torch.float32, device=dev)
+        n = len(items)
+        pack = (lib.XchgJob * n)()
+        unpack = (lib.XchgJob * n)()
+        off = 0
+        for q, (t, c, w, lay) in enumerate(items):
+            pack[q] = lib.XchgJob(t.data_ptr(), t.stride(0), int(c), int(w), lay.own_nodes_i32.data_ptr() if lay.own_count else None,
+                                  None, int(lay.own_count), off, int(lay.slots_per_rank))
+            k = lay.other_nodes_i32.numel()
+            unpack[q] = lib.XchgJob(t.data_ptr(), t.stride(0), int(c), int(w), lay.other_nodes_i32.data_ptr() if k else None,
+                                    lay.other_slots_i32.data_ptr() if k else None, int(k), off, int(lay.slots_per_rank))
+            off += lay.slots_per_rank * w
+        lib.check(lib.load().pea_rows_pack_batch(n, pack, lib.ptr(stage[self.rank]), lib.current_stream()))
+        self._all_gather_blocks(stage, 1, group)
+        lib.check(lib.load().pea_rows_unpack_batch(n, unpack, lib.ptr(stage), block, lib.current_stream()))
+
     def fill_in_ids(self, table, col, width, ids, group=None):
         """The same for an explicit list of node ids (duplicates allowed; e.g. the rows of a BPR batch): every rank
         contributes the listed rows it owns, one all-reduce of [len(ids), width] (x + 0: exact), and every listed row of

@@ -382,6 +382,18 @@ int pea_rows_unpack(const float *src, int64_t src_ld, const int32_t *src_rows, i
 int pea_rows_select_owned(const float *table, int64_t ld, int width, int64_t num_nodes, const int64_t *ids,
                           int64_t id_stride, int64_t n, int rank, int world, int tile, float *out, int32_t *err_flag,
                           void *stream);
+/* Batched pack / unpack against ONE rank-major exchange buffer (rank blocks `rank_stride` floats apart): job q moves the
+ * columns [col, col + width) of table rows nodes[0..n) to / from the rows at buf_off (floats from the start of a rank
+ * block, `width` floats per row).  pack: row k of the job goes to this rank's block (`rank_block`).  unpack: row k comes
+ * from slot slots[k] = rank * slots_per_rank + local of `buffer` (= rank 0's block).  One launch per <= 24 jobs: a sharded
+ * backward level fills in all its gradient buffers with one pack, ONE collective and one unpack. */
+typedef struct pea_xchg_job {
+    float *table; int64_t ld; int col; int width;
+    const int32_t *nodes; const int32_t *slots; int64_t n;
+    int64_t buf_off; int slots_per_rank;
+} pea_xchg_job;
+int pea_rows_pack_batch(int n_jobs, const pea_xchg_job *jobs_host, float *rank_block, void *stream);
+int pea_rows_unpack_batch(int n_jobs, const pea_xchg_job *jobs_host, const float *buffer, int64_t rank_stride, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Live per-launch timing (bench.py's roofline leg): when enabled every kernel launch of the library is
