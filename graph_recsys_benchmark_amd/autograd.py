@@ -185,11 +185,12 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             for u, tmp in shared.get('acc', []):
                 dT[:, u['t_col']:u['t_col'] + u['in_w']] += tmp
             if sharded:     # the reverse mean aggregation gathers dM rows of the forward relation's destinations
-                seen = set()
+                seen, items = set(), []
                 for u in units:
                     if u['t_col'] not in seen:
                         seen.add(u['t_col'])
-                        shard.fill_in_rows(dT, u['t_col'], u['in_w'], rev_layout(u['rel']))
+                        items.append((dT, u['t_col'], u['in_w'], rev_layout(u['rel'])))
+                shard.fill_in_rows_batch(items)         # one exchange for the level
             level_call(s, 1)
             dagg = _view(wsf, lv['off_side'], n, lv['ld_t'])
             done = set()
