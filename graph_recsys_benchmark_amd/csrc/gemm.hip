@@ -296,10 +296,12 @@ __global__ __launch_bounds__(256) void gemm_deep_kernel(const GemmBatch Bt, cons
 // temporaries beyond the fragment itself
 template <int KH>
 __device__ __forceinline__ void load_a_plain(const GemmJob &J, int64_t srow, bool rv, int kbase, float (&a)[KH]) {
+    // the two k-halves of a row interleave by float4 (kbase = chunk start + 4h, chunks 8 floats apart): one load
+    // instruction reads 32 contiguous bytes per row instead of two 16-byte pieces 128+ bytes apart
     const float *p = J.A1 + srow * J.lda1;
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
-        const int k = kbase + q * 4;
+        const int k = kbase + q * 8;
         const bool keep = rv && k < J.K1;
         const float4 t = ld4(p + (k < J.K1 ? k : 0));
         a[q * 4 + 0] = keep ? t.x : 0.f;
@@ -339,10 +341,10 @@ __global__ __launch_bounds__(1024) void gemm_deep_resident_kernel(const GemmBatc
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
         for (int kc = 0; kc < nkc; ++kc) {
-            load_a_plain<KH>(J, srow, rv, kc * 2 * KH + h * KH, a);
-            const float *bs = g_lds + ((size_t)kc * 2 * KH + h * KH) * W + r;
+            load_a_plain<KH>(J, srow, rv, kc * 2 * KH + 4 * h, a);   // a[4q + e] = k  kc * 64 + 4 (2q + h) + e
+            const float *bs = g_lds + ((size_t)kc * 2 * KH + 4 * h) * W + r;   // image row of a[kl]: + 8 (kl / 4) + kl % 4
             const bool last_partial = (kc + 1) * 2 * KH > K;            // wave-uniform
-            const int kbase = kc * 2 * KH + h * KH;                     // first image row of this lane half's 64
+            const int kbase = kc * 2 * KH + 4 * h;                      // image row of a[0] of this lane half
             // B operands in batches of 8 LDS reads per column tile, fenced: left alone, the scheduler hoists all 64 * NCT
             // reads of the chunk ahead of the MFMAs and spills
 #pragma unroll
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(1024) void gemm_deep_resident_kernel(const GemmBatc
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int kl = 8 * g + u;   // row kc * 128 + h * 64 + kl of the image, clamped in a partial last chunk
-                        bb[ct][u] = last_partial ? g_lds[(size_t)min(kbase + kl, K - 1) * W + r + 32 * ct] : bs[kl * W + 32 * ct];
+                        const int ko = 8 * (kl / 4) + kl % 4;   // interleaved k order of the fragment
+                        bb[ct][u] = last_partial ? g_lds[(size_t)min(kbase + ko, K - 1) * W + r + 32 * ct] : bs[ko * W + 32 * ct];
                     }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
