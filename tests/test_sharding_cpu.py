@@ -66,6 +66,30 @@ def _worker(rank, world, port, tile):
         ids = torch.tensor([0, n - 1, 5, 5, tile, tile - 1, 2 * tile + 3, 77], dtype=torch.int64)
         torch.testing.assert_close(shard.gather_rows(local, ids), truth[ids], rtol=0, atol=0)   # `local` is NaN off-rank
 
+        # 3c. gradient fill-ins of the sharded backward: every rank has written the rows it owns; the rows of the
+        #     relation's source nodes that other ranks own are filled in, one buffer at a time and batched (one exchange
+        #     for several buffers / relations; CPU tensors take the per-item path of fill_in_rows_batch)
+        a2i = torch.from_numpy(rel['a2i'])
+        lay2 = shard.source_layout(a2i)                                # attribute -> item: sources are attribute nodes
+        for batched in (False, True):
+            g1 = torch.full_like(truth, float('nan'))
+            g1[own] = truth[own]
+            g2 = torch.full((n, 8), float('nan'))
+            g2[own] = truth[own, :8] + 1000.0
+            if batched:
+                shard.fill_in_rows_batch([(g1, 4, 8, lay), (g2, 0, 4, lay2), (g2, 4, 4, lay)])
+            else:
+                shard.fill_in_rows(g1, 4, 8, lay)
+                shard.fill_in_rows(g2, 0, 4, lay2)
+                shard.fill_in_rows(g2, 4, 4, lay)
+            torch.testing.assert_close(g1[lay.src_nodes, 4:12], truth[lay.src_nodes, 4:12], rtol=0, atol=0)
+            torch.testing.assert_close(g2[lay2.src_nodes, 0:4], truth[lay2.src_nodes, 0:4] + 1000.0, rtol=0, atol=0)
+            torch.testing.assert_close(g2[lay.src_nodes, 4:8], truth[lay.src_nodes, 4:8] + 1000.0, rtol=0, atol=0)
+            others = torch.ones(n, dtype=torch.bool)
+            others[own] = False
+            others[lay.src_nodes] = False
+            assert torch.isnan(g1[others, 4:12]).all()                 # nothing else is touched
+
         # 4. dependency check with the oracle: a rank that knows the conv input only on (owned rows + the
         #    relation's source nodes) still gets its owned output rows right (NaN-poisoned elsewhere)
         rng = np.random.default_rng(0)
