@@ -159,6 +159,15 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = None      # torch's raw current-stream getter (one C call; torch.cuda.current_stream() builds a Stream object
+                        # and resolves the device through several Python layers: ~3 us, six times per step)
+
+
 def current_stream():
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', False)
+    if _raw_stream:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

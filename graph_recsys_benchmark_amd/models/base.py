@@ -180,12 +180,21 @@ class PEABaseRecsysModel(GraphRecsysModel):
         return getattr(self, attr)
 
     def _layer_params(self):
+        """Parameter tensors per conv layer in PARAM_SLOTS order.  The Parameter objects are looked up once (named_parameters
+        over ~20 modules was 35 % of a step's host time on the launch-bound presets) and the list is rebuilt only when a
+        module's parameter has been replaced by another object (every module._parameters entry is checked by identity)."""
+        cache = getattr(self, '_lp_cache', None)
+        if cache is not None and all(mod._parameters.get(name) is t for mod, name, t in cache[1]):
+            return cache[0]
         slots = _engine.PARAM_SLOTS[self.kind]
-        out = []
+        out, check = [], []
         for channel in self.pea_channels:
             for layer in channel.gnn_layers:
                 sd = dict(layer.named_parameters())
                 out.append(tuple(sd.get(name) for name in slots))
+                for mod in layer.modules():                       # the layer and its Linear submodules
+                    check.extend((mod, name, t) for name, t in mod._parameters.items())
+        self._lp_cache = (out, check)
         return out
 
     def forward(self, metapath_idx=None, return_stack=False):
