@@ -324,7 +324,7 @@ class PEAStackFunction(torch.autograd.Function):
         ctx.active_ids, ctx.active_rows = options.read_ids, None
         if options.read_ids is not None and engine.kind == 'gat':
             ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
-            ctx.active_rows[options.read_ids] = 1
+            ctx.active_rows.index_fill_(0, options.read_ids, 1)      # (indexed assignment of a Python scalar stages it through the host)
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
         ctx.present = [t is not None for t in flat]
         return stack
@@ -388,7 +388,7 @@ class PEALossFunction(torch.autograd.Function):
         ctx.active_rows = None
         if engine.kind == 'gat':
             ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
-            ctx.active_rows[ids] = 1
+            ctx.active_rows.index_fill_(0, ids, 1)
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
         ctx.present = [t is not None for t in flat]
         return loss
