@@ -71,6 +71,37 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def launch_ranks(cmds_envs, poll_s=0.05, grace_s=5.0):
+    """Start one child per (argv, env) pair and supervise them TOGETHER: every child is polled (not waited on in rank
+    order), and as soon as one exits non-zero the others are terminated (then killed after `grace_s`) and its code is
+    returned -- a rank that dies early must not leave its peers sitting in a collective until the NCCL watchdog or the
+    driver's own limit fires.  Returns 0 only if every child exited 0."""
+    procs = [subprocess.Popen(cmd, env=env) for cmd, env in cmds_envs]
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = abs(bad[0]) or 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(poll_s)
+    finally:
+        live = [p for p in procs if p.poll() is None]
+        for p in live:            # exact PIDs of the children started above
+            p.terminate()
+        t_end = time.time() + grace_s
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
+
+
 def self_launch(args):
     """--gpus N > 1 without an external launcher: start N fresh ranks of this script (nothing in this process has
     touched a GPU: only argparse and imports ran) and relay rank 0's JSON line.  Returns the exit code."""
@@ -78,20 +109,29 @@ def self_launch(args):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    jobs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
-    finally:
-        for p in procs:           # a rank that died takes the job down: no orphans holding a GPU
-            if p.poll() is None:
-                p.kill()
-    return rc
+        jobs.append(([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env))
+    return launch_ranks(jobs)
+
+
+HEADLINE_METRIC = 'BPR-scored edges/sec, PEAGAT MovieLens-25m, emb_dim=64, 9 metapaths'   # BASELINE.json
+
+
+def is_headline(args):
+    return args.preset == 'ml25m_shaped' and args.kind == 'gat' and args.scale == 1.0 and not args.metapaths
+
+
+def metric_name(args):
+    """BASELINE.json's metric string for the configuration it is quoted on; any other --preset / --kind / --scale /
+    --metapaths run names its own workload, so a profile file of another preset cannot be mistaken for the headline."""
+    if is_headline(args):
+        return HEADLINE_METRIC
+    return 'BPR-scored edges/sec, PEA%s %s%s%s (not the BASELINE.json headline configuration)' % (
+        args.kind.upper(), args.preset, '' if args.scale == 1.0 else ' x %g' % args.scale,
+        ', first %d metapaths' % args.metapaths if args.metapaths else '')
 
 
 def build_model(dataset, kind, device):
@@ -298,11 +338,17 @@ def main():
     device = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        # a rank that never arrives (or dies in a collective) ends the job after two minutes, not after the default 10-30
+        limit = datetime.timedelta(seconds=int(os.environ.get('PEA_DIST_TIMEOUT_S', '120')))
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            dist.init_process_group('nccl', device_id=device, timeout=limit)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit)
     _lib.require_device()
+    if world > 1:
+        from graph_recsys_benchmark_amd.sharding import ShardLayout
+        ShardLayout.verify_inplace_all_gather(device if args.backend == 'nccl' else 'cpu')
 
     dataset = SyntheticHIN(args.preset, seed=2019, scale=args.scale)
     if args.metapaths:
@@ -393,7 +439,7 @@ def main():
     floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 / world
 
     out = {
-        'metric': 'BPR-scored edges/sec, PEAGAT MovieLens-25m, emb_dim=64, 9 metapaths',
+        'metric': metric_name(args),
         'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
@@ -402,6 +448,7 @@ def main():
                                % (args.preset, args.kind.upper(), dataset.num_nodes, dataset.spec['num_metapaths'],
                                   messages, dataset.spec['emb_dim'], dataset.spec['hidden_size'],
                                   dataset.spec['repr_dim'], b),
+                   'headline': is_headline(args),
                    'parallelism': 'rows%d' % world if world > 1 else 'single', 'loss': float(loss),
                    'batch_h2d': 'excluded: the %d-byte batch is resident in HBM when the timed region starts (bench '
                                 'contract); over PCIe it is a ~10 us copy' % batch_host.nbytes},

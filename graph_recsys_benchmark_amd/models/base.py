@@ -147,6 +147,10 @@ class PEABaseRecsysModel(GraphRecsysModel):
         torch.distributed must be initialised (backend 'nccl' = RCCL on the GPUs)."""
         self._shard = (int(rank), int(world), int(tile))
         self._engine = self._train_engine = self._plan = None
+        if world > 1 and self.x.is_cuda:
+            # RCCL: the in-place all-gather form of the exchanges is checked against the out-of-place one, once per process
+            from ..sharding import ShardLayout
+            ShardLayout.verify_inplace_all_gather(self.x.device)
         return self
 
     def reset_parameters(self):

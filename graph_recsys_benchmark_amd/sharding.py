@@ -88,7 +88,8 @@ class SourceLayout:
 
 
 class ShardLayout:
-    _inplace_ok = True   # see _all_gather_blocks
+    _inplace_checked = False
+    _inplace_ok = True   # set by verify_inplace_all_gather (start-up comparison with the out-of-place form)
 
     def __init__(self, num_nodes, rank=0, world=1, tile=256):
         if not (0 <= rank < world) or tile <= 0:
@@ -98,6 +99,36 @@ class ShardLayout:
         self._gather_plan = {}
         self._flags = {}
         self.dry = False   # True: skip the collectives (single-process rehearsal of one rank's compute + host work)
+
+    @classmethod
+    def verify_inplace_all_gather(cls, device, group=None, rows=4096):
+        """Start-up self-check (backend 'nccl' = RCCL, world > 1): the in-place all-gather form every exchange uses
+        (send block = this rank's slice of the receive buffer) is run once on a small buffer and COMPARED with the
+        out-of-place form; `_inplace_ok` is set from that comparison on all ranks together (MIN over the ranks), not from an
+        exception -- an aliasing problem that shows up as wrong data, or asynchronously, would otherwise go unnoticed.
+        Returns the verdict.  Other backends (gloo rehearsal) do not alias buffers: nothing to check."""
+        if not dist.is_available() or not dist.is_initialized():
+            return cls._inplace_ok
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if world == 1 or dist.get_backend(group) != 'nccl' or cls._inplace_checked:
+            return cls._inplace_ok
+        cls._inplace_checked = True
+        mine = (torch.arange(rows, device=device, dtype=torch.float32) + float(rank * rows)) * 0.5
+        want = torch.empty(world * rows, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(want, mine, group=group)
+        buf = torch.full((world * rows,), -1.0, dtype=torch.float32, device=device)
+        buf[rank * rows:(rank + 1) * rows] = mine
+        ok = True
+        try:
+            dist.all_gather_into_tensor(buf, buf[rank * rows:(rank + 1) * rows], group=group)
+            torch.cuda.synchronize(device)
+            ok = bool(torch.equal(buf, want))
+        except RuntimeError:
+            ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        cls._inplace_ok = bool(int(flag.item()))
+        return cls._inplace_ok
 
     def owner(self, nodes):
         return torch.div(nodes, self.tile, rounding_mode='floor') % self.world
@@ -127,12 +158,10 @@ class ShardLayout:
             # RCCL all-gather IN PLACE: the send block is this rank's slice of the receive buffer (ncclAllGather's
             # documented in-place form, sendbuff == recvbuff + rank * count).  Should a torch / RCCL build refuse aliased
             # buffers, the send block is copied out once and for all later calls (slower by one copy, same result).
+            # `_inplace_ok` comes from verify_inplace_all_gather (a data comparison at start-up, all ranks agree).
             if ShardLayout._inplace_ok:
-                try:
-                    dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=group)
-                except RuntimeError:
-                    ShardLayout._inplace_ok = False
-            if not ShardLayout._inplace_ok:
+                dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=group)
+            else:
                 dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1).clone(), group=group)
         else:                                                                          # gloo (CPU tests / rehearsal)
             parts = [torch.empty(mine.shape, dtype=buf.dtype) for _ in range(self.world)]
