@@ -62,8 +62,11 @@ def parse(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='skip the eval-variant and 13-metapath legs')
     ap.add_argument('--graph', action='store_true', help='N=1 only: replay the forward from a captured hipGraph\n'
                     '(PEAEngine.forward_graphed; for launch-bound presets such as ml_small)')
-    ap.add_argument('--train-steps', type=int, default=0, help='also time this many full training steps '
-                    '(zero_grad, loss, backward, Adam step: reference solvers.py:213-216); extra field, N=1 only')
+    ap.add_argument('--train-steps', type=int, default=-1, help='also time this many full training steps '
+                    '(zero_grad, loss, backward, Adam step: reference solvers.py:213-216) -> `training_step`; default: 6 on '
+                    'one GPU, 0 on a sharded run (give a count to time the sharded training step too)')
+    ap.add_argument('--grad-check-triples', type=int, default=48, help='training leg: full-size gradient check of a sub-batch '
+                    'of this many triples against float64 autograd on its 2-hop neighbourhood (oracle/grad64.py); 0 = skip')
     ap.add_argument('--emulate-world', type=int, default=0, help='single process: time ONE rank (rank 0) of a sharded run of\n'
                     'this many ranks with the collectives skipped (results are wrong, timings are per-rank compute + host work)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' "
@@ -223,13 +226,15 @@ def cpu_baseline(dataset, model, kind, samples):
                        'microseconds, excluded)' % (len(p_all), msgs, len(times), dt)), fused
 
 
-def load_traffic(preset, kind, scale, world):
+def load_traffic(preset, kind, scale, world, leg=None):
     """{kernel: {hbm_bytes_per_launch, l2_hit_rate, ...}} measured with rocprofv3 PMC passes for THIS preset / kind / scale
     on one GPU (profiles/traffic.json, written by profiles/summarize.py; key '<preset>/<kind>' at full scale,
     '<preset>@<scale>/<kind>' otherwise), or {}.  A rank of a sharded run gathers from the SAME source table through the
     same source slices (rows are sharded, sources are not), so it takes the L2 hit rate of the one-GPU profile to name
     the cache tier -- marked as such -- and no byte counts (those are per whole-graph launch)."""
     key = '%s/%s' % (preset, kind) if scale == 1.0 else '%s@%g/%s' % (preset, scale, kind)
+    if leg:
+        key += '/' + leg            # e.g. 'ml25m_shaped/gat/train': the PMC passes of the training step
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             tab = json.load(f).get(key, {})
@@ -480,33 +485,10 @@ def main():
         out['kernels_ms_per_step'] = {k: round(v[1] / args.steps, 4) for k, v in
                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}
     single = world == 1 and args.emulate_world <= 1
-    if args.train_steps > 0:          # sharded too: every rank steps its replica with the all-reduced gradients
-        # torch.optim.Adam as the reference builds it (solvers.py:141-146), in torch's single-kernel form (fused=True: the
-        # default foreach form runs ~9 passes over the 70 MB embedding table and its moments, 0.36 ms of the step)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3, fused=True)
-
-        def train_step():
-            opt.zero_grad()
-            l = model.loss(batch)
-            l.backward()
-            opt.step()
-            return l
-
-        for _ in range(2):
-            train_step()
-        tt, l = timed_region(train_step, args.train_steps)
-        tt /= args.train_steps
-        out['training_step'] = {'ms_per_step': tt * 1e3, 'steps': args.train_steps, 'loss': float(l),
-                                'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step (torch.optim.Adam, fused=True)'
-                                        + (' (row-sharded over %d ranks: gradient-row fill-ins, gradient all-reduce, dx '
-                                           'all-gather)' % world if world > 1 else '')}
-        if profile:
-            lib.pea_profile_enable(1)
-            train_step()
-            torch.cuda.synchronize()
-            lib.pea_profile_enable(0)
-            out['training_step']['hip_kernels_ms'] = {k: round(v[1], 3) for k, v in
-                                                      sorted(read_profile().items(), key=lambda kv: -kv[1][1])}
+    train_steps = args.train_steps if args.train_steps >= 0 else (6 if single else 0)
+    if train_steps > 0:          # sharded too: every rank steps its replica with the all-reduced gradients
+        out['training_step'] = training_leg(dataset, model, batch, args, timed_region, train_steps, world, profile,
+                                            rank == 0 and single and not args.no_cpu_baseline)
     if single and not args.no_extras:
         out['eval_variant'] = eval_variant(dataset, model, args, timed_region)
     if rank == 0 and single and not args.no_cpu_baseline:
@@ -526,6 +508,98 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def training_leg(dataset, model, batch, args, timed_region, train_steps, world, profile, with_check):
+    """The reference's training step (solvers.py:213-216): zero_grad, loss = model.loss(batch) on the full-graph forward,
+    loss.backward() through the HIP conv stack, optimizer.step() -- timed like the headline step, then one more step with
+    HIP events around every launch.  `roofline` is the dominant kernel of the step, built like the forward's (for a
+    gradient gather: row chunk + index (+ side record) of every message once / its time, against the gather ceiling of the
+    cache tier the rows come from; PMC figures from profiles/traffic.json key '<preset>/<kind>/train').  `gradient_check`:
+    the same model's gradients of a sub-batch at FULL graph size against float64 autograd on the sub-batch's complete 2-hop
+    in-neighbourhood (oracle/grad64.py: exact, the loss reads nothing else)."""
+    lib = __import__('graph_recsys_benchmark_amd._lib', fromlist=['_lib']).load()
+    # torch.optim.Adam as the reference builds it (solvers.py:141-146), in torch's single-kernel form (fused=True: the
+    # default foreach form runs ~9 passes over the 70 MB embedding table and its moments, 0.36 ms of the step)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3, fused=True)
+    res = {}
+    if with_check and args.grad_check_triples > 0 and args.kind in ('gat', 'sage'):
+        res['gradient_check'] = gradient_check(dataset, model, batch[:args.grad_check_triples], args.kind)
+
+    def train_step():
+        opt.zero_grad()
+        l = model.loss(batch)
+        l.backward()
+        opt.step()
+        return l
+
+    for _ in range(2):
+        train_step()
+    tt, l = timed_region(train_step, train_steps)
+    tt /= train_steps
+    res.update({'ms_per_step': tt * 1e3, 'steps': train_steps, 'loss': float(l),
+                'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step (torch.optim.Adam, fused=True)'
+                        + (' (row-sharded over %d ranks: gradient-row fill-ins, gradient all-reduce, dx all-gather)' % world
+                           if world > 1 else '')})
+    if profile:
+        n_prof = 3
+        lib.pea_profile_enable(1)
+        for _ in range(n_prof):
+            train_step()
+        torch.cuda.synchronize()
+        lib.pea_profile_enable(0)
+        prof = read_profile()
+        res['hip_kernels_ms'] = {k: round(v[1] / n_prof, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        res['hip_kernels_ms_sum'] = round(sum(v[1] for v in prof.values()) / n_prof, 3)
+        tab = load_traffic(args.preset, args.kind, args.scale, max(world, args.emulate_world or 1), leg='train')
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        res['roofline'] = kernel_roofline(dom[0], dom[1], tab, {})
+        bwd = {k: v for k, v in prof.items() if k.startswith('gat_bwd') and v[3] > 0}
+        if bwd:
+            g = max(bwd.items(), key=lambda kv: kv[1][1])
+            if g[0] != dom[0]:
+                res['roofline_backward_gather'] = kernel_roofline(g[0], g[1], tab, {})
+    return res
+
+
+def gradient_check(dataset, model, sub_batch, kind):
+    """Gradients of loss(sub_batch) at full graph size: HIP (model.loss(...).backward()) against float64 torch autograd on
+    the sub-batch's 2-hop in-neighbourhood.  Per tensor: max |hip - f64| / max |f64| (the bound tests/test_gpu_backward.py
+    uses is 2e-4); x: over all N rows (rows outside the neighbourhood must be exactly zero)."""
+    from graph_recsys_benchmark_amd.utils import metapath_table
+    from oracle.grad64 import f64_subgraph_loss_and_grads
+    t0 = time.perf_counter()
+    model.zero_grad()
+    loss = model.loss(sub_batch)
+    loss.backward()
+    got = {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in model.named_parameters()}
+    model.zero_grad()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    table = metapath_table(dataset.dataset_args())[:dataset.spec['num_metapaths']]
+    cache, edges = {}, []
+    for steps in table:
+        row = []
+        for rel, flipped in steps:
+            if (rel, flipped) not in cache:
+                e = dataset.edge_index_nps[rel].astype(np.int64)
+                cache[(rel, flipped)] = np.ascontiguousarray(e[::-1]) if flipped else e
+            row.append(cache[(rel, flipped)])
+        edges.append(row)
+    want_loss, want, touched = f64_subgraph_loss_and_grads(kind, sd, edges, sub_batch.cpu().numpy())
+    worst, worst_name = 0.0, None
+    for k, w in want.items():
+        rel_err = float(np.abs(got[k] - w).max() / max(np.abs(w).max(), 1e-30))
+        if rel_err > worst:
+            worst, worst_name = rel_err, k
+    outside = np.ones(want['x'].shape[0], bool)
+    outside[touched] = False
+    x_rel = float(np.abs(got['x'] - want['x']).max() / max(np.abs(want['x']).max(), 1e-30))
+    return {'triples': int(sub_batch.shape[0]), 'tensors': len(want), 'loss_rel_err': abs(float(loss) - want_loss) / abs(want_loss),
+            'worst_rel_err': worst, 'worst_tensor': worst_name, 'x_grad_rel_err': x_rel,
+            'x_rows_in_neighbourhood': int(touched.size), 'x_grad_nonzero_outside_neighbourhood': int(np.count_nonzero(got['x'][outside])),
+            'bound_in_tests': 2e-4, 'seconds': round(time.perf_counter() - t0, 1),
+            'what': 'every parameter gradient of loss(sub-batch) on the FULL graph vs float64 autograd on the sub-batch\'s '
+                    'complete 2-hop in-neighbourhood (oracle/grad64.py); rel err = max |diff| / max |f64| per tensor'}
 
 
 def eval_variant(dataset, model, args, timed_region):

@@ -369,14 +369,32 @@ __global__ __launch_bounds__(kBlock) void bwd_merge_kernel(const AggLaunch L) {
 
 template <int G, int MODE, int F4T>
 int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t stream) {
-    const char *nm = MODE == AGG_GAT_BWD_D ? "gat_bwd_dst" : "gat_bwd_src";
+    // launches whose rows / gathered rows are filtered by row_active (the last layer: only the BPR batch's rows carry a
+    // gradient) get their own name: the live messages are not known on the host, so no byte count is attributed to them
+    bool sparse = false;
+    for (int i = 0; i < n_sel; ++i) sparse = sparse || base.g[sel[i]].row_active != nullptr;
+    // names as profiles/summarize.py derives them from rocprofv3's kernel names (bwd_rows_kernel<G, MODE, F4T>)
+    static char names[2][32];
+    if (!names[0][0]) {
+        snprintf(names[0], sizeof(names[0]), "gat_bwd_%s_g%d", MODE == AGG_GAT_BWD_D ? "dst" : "src", G);
+        snprintf(names[1], sizeof(names[1]), "gat_bwd_%s_g%d_batch", MODE == AGG_GAT_BWD_D ? "dst" : "src", G);
+    }
+    const char *nm = names[sparse ? 1 : 0];
     AggLaunch L;
     {   // long rows + hub chunks first, short rows behind them, one launch
         L.n_groups = 0;
         int blocks = 0, sblocks = 0;
+        // bytes the launch pulls through the memory system, each once per message (bench.py's live roofline): the gathered
+        // row chunk (D: T_j; S: the output-gradient row g_i) + the 4-byte index (+ S: the 16-byte side record per head)
+        double pulled = 0.0, table = 0.0;
         for (int i = 0; i < n_sel; ++i) {
             const AggGroup &g = base.g[sel[i]];
             if (g.n_short <= 0 && g.n_long <= 0) continue;
+            if (!sparse) {
+                const double per = 4.0 * g.W + 4.0 + (MODE == AGG_GAT_BWD_S ? 16.0 * (g.W / g.F) : 0.0);
+                pulled += per * (g.msgs_short + g.msgs_long);
+                table = std::max(table, g.table_rows * 4.0 * g.W);
+            }
             L.blk_start[L.n_groups] = blocks;
             L.blk_short[L.n_groups] = sblocks;
             L.g[L.n_groups++] = g;
@@ -387,7 +405,7 @@ int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         L.blk_short[L.n_groups] = sblocks;
         L.n_long_blocks = blocks;
         if (blocks + sblocks > 0) {
-            ProfScope ps(nm, stream, 0.0);
+            ProfScope ps(nm, stream, pulled, pulled, table);
             hipLaunchKernelGGL((bwd_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
             PEA_HIP(hipGetLastError());
         }
@@ -404,7 +422,7 @@ int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         }
         L.blk_start[L.n_groups] = blocks;
         if (blocks > 0) {
-            ProfScope ps(nm, stream, 0.0);
+            ProfScope ps(MODE == AGG_GAT_BWD_D ? "gat_bwd_dst_merge" : "gat_bwd_src_merge", stream, 0.0);
             hipLaunchKernelGGL((bwd_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
             PEA_HIP(hipGetLastError());
         }

@@ -211,6 +211,9 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             D.short_rows = R.short_rows + R.n_short0;
             D.n_short = R.n_short - R.n_short0;
         }
+        D.msgs_short = (double)R.edges_short;   // bookkeeping for the live roofline (agg_bwd.hip: launch_bwd_g)
+        D.msgs_long = (double)R.edges_long;
+        D.table_rows = (sharded && level > 0) ? (double)R.slots_per_rank * plan->shard_world : (double)R.src_span;
         if (part_a) gd.push_back(D);
         // S pass: source rows = destination rows of the reversed relation, gathers g_i and the side records
         AggGroup S = a;
@@ -225,6 +228,9 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         S.out = dT + g.col;
         S.ld_out = L.ld_t;
         S.deg0_self = loops ? R.deg0 : nullptr;
+        S.msgs_short = (double)Rr.edges_short;
+        S.msgs_long = (double)Rr.edges_long;
+        S.table_rows = (double)Rr.src_span;
         if (part_b) gsrc.push_back(S);
     }
     // all groups of the level side by side in one set of launches per pass (the S pass of a group reads what the D pass

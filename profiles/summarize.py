@@ -17,6 +17,10 @@ def short(name):
     if m:
         mode = {'0': 'gat', '1': 'gcn', '2': 'mean'}[m.group(3)]
         return '%s_g%s_%s' % (m.group(1).replace('_kernel', ''), m.group(2), mode)
+    m = re.search(r'bwd_(rows|merge)_kernel<(\d+), *(\d+)', name)
+    if m:                        # backward gather passes: MODE 3 = D (destination rows), 4 = S (source rows); bench.py names
+        side = 'dst' if m.group(3) == '3' else 'src'
+        return 'gat_bwd_%s_g%s' % (side, m.group(2)) if m.group(1) == 'rows' else 'gat_bwd_%s_merge' % side
     m = re.search(r'(gemm_mfma|gemm_persist|gemm_skinny)_kernel<(\d+)', name)
     if m:                        # bench.py names: gemm_persist = gemm_mfma_shared / _batch, gemm_skinny = gemm_mfma_narrow
         return '%s_k%s' % (m.group(1), m.group(2))
