@@ -523,8 +523,6 @@ def training_leg(dataset, model, batch, args, timed_region, train_steps, world, 
     # default foreach form runs ~9 passes over the 70 MB embedding table and its moments, 0.36 ms of the step)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3, fused=True)
     res = {}
-    if with_check and args.grad_check_triples > 0 and args.kind in ('gat', 'sage'):
-        res['gradient_check'] = gradient_check(dataset, model, batch[:args.grad_check_triples], args.kind)
 
     def train_step():
         opt.zero_grad()
@@ -559,6 +557,10 @@ def training_leg(dataset, model, batch, args, timed_region, train_steps, world, 
             g = max(bwd.items(), key=lambda kv: kv[1][1])
             if g[0] != dom[0]:
                 res['roofline_backward_gather'] = kernel_roofline(g[0], g[1], tab, {})
+    # after the timed steps: the float64 side is ~20 s of multi-threaded CPU work, whose worker threads would still be
+    # spinning next to the (host-bound) enqueue loop of the steps timed above
+    if with_check and args.grad_check_triples > 0 and args.kind in ('gat', 'sage'):
+        res['gradient_check'] = gradient_check(dataset, model, batch[:args.grad_check_triples], args.kind)
     return res
 
 
@@ -586,20 +588,29 @@ def gradient_check(dataset, model, sub_batch, kind):
             row.append(cache[(rel, flipped)])
         edges.append(row)
     want_loss, want, touched = f64_subgraph_loss_and_grads(kind, sd, edges, sub_batch.cpu().numpy())
-    worst, worst_name = 0.0, None
+    # a tensor's error is measured against ITS largest float64 gradient, floored at 1e-6 of the largest gradient of any
+    # tensor: gradients that vanish analytically (a last-layer att_i: a per-row shift of all logits only matters through the
+    # leaky-relu kink) are sums of O(global) terms that cancel, so their fp32 noise is relative to those terms
+    g_max = max(float(np.abs(w).max()) for w in want.values())
+    worst, worst_name, per = 0.0, None, []
     for k, w in want.items():
-        rel_err = float(np.abs(got[k] - w).max() / max(np.abs(w).max(), 1e-30))
+        err, scale = float(np.abs(got[k] - w).max()), float(np.abs(w).max())
+        rel_err = err / max(scale, 1e-6 * g_max)
+        per.append((rel_err, k, err, scale))
         if rel_err > worst:
             worst, worst_name = rel_err, k
+    per.sort(reverse=True)
     outside = np.ones(want['x'].shape[0], bool)
     outside[touched] = False
     x_rel = float(np.abs(got['x'] - want['x']).max() / max(np.abs(want['x']).max(), 1e-30))
     return {'triples': int(sub_batch.shape[0]), 'tensors': len(want), 'loss_rel_err': abs(float(loss) - want_loss) / abs(want_loss),
-            'worst_rel_err': worst, 'worst_tensor': worst_name, 'x_grad_rel_err': x_rel,
+            'worst_rel_err': worst, 'worst_tensor': worst_name, 'largest_gradient': g_max,
+            'worst_three': [{'tensor': k, 'rel_err': r, 'abs_err': e, 'max_abs_f64': sc} for r, k, e, sc in per[:3]],
+            'x_grad_rel_err': x_rel,
             'x_rows_in_neighbourhood': int(touched.size), 'x_grad_nonzero_outside_neighbourhood': int(np.count_nonzero(got['x'][outside])),
             'bound_in_tests': 2e-4, 'seconds': round(time.perf_counter() - t0, 1),
             'what': 'every parameter gradient of loss(sub-batch) on the FULL graph vs float64 autograd on the sub-batch\'s '
-                    'complete 2-hop in-neighbourhood (oracle/grad64.py); rel err = max |diff| / max |f64| per tensor'}
+                    'complete 2-hop in-neighbourhood (oracle/grad64.py); rel err = max |diff| / max(max |f64| of the tensor, 1e-6 x the largest gradient of any tensor)'}
 
 
 def eval_variant(dataset, model, args, timed_region):

@@ -54,6 +54,12 @@ class DenseJob(C.Structure):
                 ('n_out', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64), ('gate', C.c_void_p), ('ld_gate', C.c_int64)]
 
 
+class StageOpts(C.Structure):
+    _fields_ = [('part', C.c_int), ('sel_ids', C.c_void_p), ('sel_stride', C.c_int64), ('n_sel', C.c_int64),
+                ('sel_out', C.c_void_p), ('err_flag', C.c_void_p)]
+
+
+PART_ALL, PART_SOURCES, PART_REST = 0, 1, 2     # include/peahip.h PEA_PART_*
 BWD_PREMASKED = 0x100     # include/peahip.h PEA_BWD_PREMASKED
 
 # every symbol include/peahip.h declares: name -> (restype, argtypes)
@@ -76,6 +82,9 @@ SIGNATURES = {
     'pea_model_num_stages': (_int, [_vp]),
     'pea_model_forward_stage': (_int, [_vp, _int, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
     'pea_model_forward_stage_train': (_int, [_vp, _int, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
+    'pea_plan_set_owned_split': (_int, [_vp, _i64]),
+    'pea_model_forward_part': (_int, [_vp, _int, C.POINTER(StageOpts), C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
+    'pea_model_stage_fills_exchange': (_int, [_vp, _int]),
     'pea_model_num_exchanges': (_int, [_vp, _int]),
     'pea_model_exchange_desc': (_int, [_vp, _int, _int, C.POINTER(ExchangeDesc)]),
     'pea_model_forward_train': (_int, [_vp, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),

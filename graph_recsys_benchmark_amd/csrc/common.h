@@ -126,6 +126,7 @@ struct pea_plan {
     float *ones = nullptr;      // device [N] of 1.0f (SAGE backward)
     int *owned_rows = nullptr;  // device, sharded plans only
     int64_t n_owned = 0;
+    int64_t n_owned_first = -1; // pea_plan_set_owned_split: the first rows of owned_rows are the ones other ranks read (-1: unset)
 };
 
 namespace pea {
@@ -320,6 +321,11 @@ struct Mlp2Chan {
     const unsigned char *deg0;            // [N] 1 = no incoming edge under the channel's first relation
     const float *dinv;                    // GCN: deg^-1/2 of the first relation (node-indexed), else null
     int a0_col, t1_col;                   // column of the channel in A_0 / T_1
+    // sharded: rows that are gather sources of the second layer also go straight into the exchange buffer of the
+    // channel's layer-2 group (x_slot[row] >= 0: row slot of that buffer; the pack launch of round 2 is gone)
+    const int *x_slot;
+    float *x_buf;                         // exchange buffer + the channel's column inside the group
+    int x_ld;
 };
 struct Mlp2Launch {
     int kind, n, emb, hid, out, per_pass;
@@ -352,13 +358,22 @@ constexpr int kMaxChannels = 64;
 struct ChanCols {
     int c[kMaxChannels];
 };
+// optional batch-row selection riding in the fusion launch of a sharded rank: sel_out[k] = the fused row of node
+// ids[k * id_stride] when this rank owns it (row / tile % world == rank), zeros otherwise -- what the loss all-reduce sums
+struct FuseSelect {
+    const int64_t *ids = nullptr;
+    int64_t id_stride = 1, n = 0;
+    float *out = nullptr;      // [n, R]
+    int *err = nullptr;        // |= 1 when an id is outside [0, N)
+    int rank = 0, world = 1, tile = 1;
+};
 int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const ChanCols &col_of_channel,
                 const float *att, int masked, int mode, const int *rows, int64_t n_rows, float *out,
-                float *out_stack, hipStream_t stream);
+                float *out_stack, hipStream_t stream, const FuseSelect *sel = nullptr);
 
 int model_forward(pea_model *m, int stage, const float *const *params, const float *x, int64_t ldx, const float *att,
                   int masked, float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x,
-                  int relu_last, hipStream_t stream, bool training);
+                  int relu_last, hipStream_t stream, bool training, int part = 0, const FuseSelect *sel = nullptr);
 
 }  // namespace pea
 float *aligned_ws(void *workspace);

@@ -3,6 +3,7 @@
 //   bpr kernels   models/base.py:208-214 (predict) + models/base.py:46-48 (-sum log sigmoid(pos-neg))
 //   rank kernel   solvers.py:85-96 (score 1 + C-1 candidates, rank of the positive, auc, eval loss)
 // All reductions have a fixed order (no float atomics): results are bitwise reproducible.
+#include <algorithm>
 #include <mutex>
 
 #include "common.h"
@@ -14,16 +15,34 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 
 // G lanes x float4 cover the R columns of one node; 64/G nodes per wave.  Softmax over the P channels
 // is taken online in channel order.
+// Sharded ranks: workgroups past the `fuse_blocks` that cover the rank's own rows fuse the rows a BPR batch names
+// (FuseSelect): the same arithmetic on the same stack row as the table entry, written to sel.out[k] when this rank owns the
+// node, zeros otherwise (the loss all-reduce sums these; round 2 ran a separate select launch over the finished table).
 template <int G>
 __global__ __launch_bounds__(256) void fuse_kernel(int64_t n_rows, const int *__restrict__ rows, int P, int R,
                                                    const float *__restrict__ stack, int64_t ld,
                                                    const ChanCols col_of_channel,
                                                    const float *__restrict__ att, int masked, int mode,
-                                                   float *__restrict__ out, float *__restrict__ out_stack) {
-    const int64_t item = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+                                                   float *__restrict__ out, float *__restrict__ out_stack,
+                                                   unsigned fuse_blocks, const FuseSelect sel, int64_t N) {
+    const bool pick = blockIdx.x >= fuse_blocks;
+    const int64_t item = (int64_t)(pick ? blockIdx.x - fuse_blocks : blockIdx.x) * (256 / G) + threadIdx.x / G;
     const int sl = threadIdx.x % G;
-    const bool valid = item < n_rows;
-    const int64_t n = valid ? (rows ? rows[item] : item) : 0;
+    bool valid = item < (pick ? sel.n : n_rows);
+    int64_t n = 0;
+    if (pick) {
+        const int64_t id = valid ? sel.ids[item * sel.id_stride] : 0;
+        const bool in_range = id >= 0 && id < N;
+        if (valid && !in_range && sl == 0) atomicOr(sel.err, 1);
+        const bool mine = in_range && (id / sel.tile) % sel.world == sel.rank;
+        if (valid && !mine && sl * 4 < R) *reinterpret_cast<float4 *>(sel.out + item * R + sl * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        valid = valid && mine;
+        n = valid ? id : 0;
+        out_stack = nullptr;
+    } else {
+        n = valid ? (rows ? rows[item] : item) : 0;
+    }
+    float *dst_row = pick ? sel.out + item * R : (out ? out + n * R : nullptr);
     const bool active = valid && sl * 4 < R;
     const int c4 = sl * 4 < R ? sl * 4 : 0;
     float m = -3.0e38f, s = 0.f;
@@ -49,9 +68,9 @@ __global__ __launch_bounds__(256) void fuse_kernel(int64_t n_rows, const int *__
         acc.w = acc.w * f + w * x.w;
         m = mn;
     }
-    if (!active || !out) return;
+    if (!active || !dst_row) return;
     const float inv = mode == PEA_FUSE_MEAN ? 1.0f / (float)P : 1.0f / s;
-    *reinterpret_cast<float4 *>(out + n * R + c4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    *reinterpret_cast<float4 *>(dst_row + c4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
 // fc2(relu(fc1([u || i])))  with fc1_w [R, 2R] staged in LDS by the caller
@@ -276,21 +295,28 @@ int lanes_for_r(int R) {
 
 int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const ChanCols &col_of_channel,
                 const float *att, int masked, int mode, const int *rows, int64_t n_rows, float *out,
-                float *out_stack, hipStream_t stream) {
+                float *out_stack, hipStream_t stream, const FuseSelect *sel_in) {
     PEA_REQUIRE(P > 0 && P <= kMaxChannels && R > 0 && R % 4 == 0 && R <= 256, PEA_ERR_ARG,
                 "fuse: P=%d R=%d (P <= 64, R a multiple of 4 and <= 256)", P, R);
     PEA_REQUIRE(masked < P, PEA_ERR_ARG, "fuse: masked channel %d out of range (P=%d)", masked, P);
     PEA_REQUIRE(mode == PEA_FUSE_MEAN || att != nullptr, PEA_ERR_ARG, "fuse: att is required for 'att' fusion");
     PEA_REQUIRE(ld % 4 == 0, PEA_ERR_ARG, "fuse: stack row stride must be a multiple of 4");
     if (!rows) n_rows = N;
-    if (n_rows <= 0) return PEA_OK;
+    FuseSelect sel;
+    if (sel_in && sel_in->n > 0) {
+        sel = *sel_in;
+        PEA_REQUIRE(sel.ids && sel.out && sel.err && sel.world >= 1 && sel.tile >= 1 && out != nullptr, PEA_ERR_ARG,
+                    "fuse: batch-row selection needs ids, an output, an error flag and the fused table");
+    }
+    if (n_rows <= 0 && sel.n <= 0) return PEA_OK;
     const int G = lanes_for_r(R);
-    ProfScope ps("fuse", stream, 4.0 * (double)n_rows * R * (P + 1));
-    const unsigned blocks = (unsigned)((n_rows + (256 / G) - 1) / (256 / G));
+    ProfScope ps("fuse", stream, 4.0 * (double)(n_rows + sel.n) * R * (P + 1));
+    const unsigned fuse_blocks = (unsigned)((std::max<int64_t>(n_rows, 0) + (256 / G) - 1) / (256 / G));
+    const unsigned blocks = fuse_blocks + (unsigned)((sel.n + (256 / G) - 1) / (256 / G));
 #define PEA_FUSE_CASE(g)                                                                                       \
     case g:                                                                                                    \
         hipLaunchKernelGGL(fuse_kernel<g>, dim3(blocks), dim3(256), 0, stream, n_rows, rows, P, R, stack, ld, \
-                           col_of_channel, att, masked, mode, out, out_stack);                                 \
+                           col_of_channel, att, masked, mode, out, out_stack, fuse_blocks, sel, N);            \
         break;
     switch (G) {
         PEA_FUSE_CASE(1)
@@ -301,7 +327,7 @@ int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const C
         PEA_FUSE_CASE(32)
         default:
             hipLaunchKernelGGL(fuse_kernel<64>, dim3(blocks), dim3(256), 0, stream, n_rows, rows, P, R, stack, ld,
-                               col_of_channel, att, masked, mode, out, out_stack);
+                               col_of_channel, att, masked, mode, out, out_stack, fuse_blocks, sel, N);
     }
 #undef PEA_FUSE_CASE
     PEA_HIP(hipGetLastError());

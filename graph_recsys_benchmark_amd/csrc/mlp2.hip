@@ -205,11 +205,16 @@ __global__ __launch_bounds__((Mlp2Cfg<ET, HT>::kThreads)) void mlp2_kernel(const
             }
             if (cur.valid) {
                 float *dst = L.t1 + cur.row * L.ld_t1 + C.t1_col;
+                const int slot = C.x_slot ? C.x_slot[cur.row] : -1;   // sharded: a gather source of layer 2 -> its exchange row too
+                float *dst_x = C.x_buf + (int64_t)(slot < 0 ? 0 : slot) * C.x_ld;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 = outputs 8g + 4 half .. + 3
                     const int j0 = 8 * g + 4 * half;
-                    if (j0 < L.out)
-                        *reinterpret_cast<float4 *>(dst + j0) = make_float4(out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]);
+                    if (j0 < L.out) {
+                        const float4 o = make_float4(out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]);
+                        *reinterpret_cast<float4 *>(dst + j0) = o;
+                        if (slot >= 0) *reinterpret_cast<float4 *>(dst_x + j0) = o;
+                    }
                 }
             }
             cur = nxt;
@@ -326,12 +331,15 @@ __global__ __launch_bounds__(512) void mlp2_sage_kernel(const Mlp2Launch L, cons
         if (cur_valid) {
             float *dst_t = L.t1 + cur_row * L.ld_t1 + C.t1_col;
             float *dst_r = L.r1 + cur_row * L.ld_r1 + C.r1_col;
+            const int slot = C.x_slot ? C.x_slot[cur_row] : -1;   // sharded: a gather source of layer 2 -> its exchange row too
+            float *dst_x = C.x_buf + (int64_t)(slot < 0 ? 0 : slot) * C.x_ld;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 = outputs 8g + 4 half .. + 3
                 const int j0 = 8 * g + 4 * half;
                 float4 o = make_float4(out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]);
                 if (j0 < L.out) {
                     *reinterpret_cast<float4 *>(dst_t + j0) = o;
+                    if (slot >= 0) *reinterpret_cast<float4 *>(dst_x + j0) = o;
                 } else if (j0 < 2 * L.out) {
                     const int j = j0 - L.out;
                     if (C.b1) {

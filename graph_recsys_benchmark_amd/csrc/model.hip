@@ -400,7 +400,7 @@ int init_model(pea_model *m, const pea_plan *plan, const pea_model_desc *desc) {
 // entry points); relu_last applies relu to last layers too.
 int model_forward(pea_model *m, int stage, const float *const *params, const float *x, int64_t ldx, const float *att,
                   int masked, float *wsf, float *out_repr, float *out_stack, float *out_x, int64_t ld_out_x, int relu_last,
-                  hipStream_t stream, bool training) {
+                  hipStream_t stream, bool training, int part, const FuseSelect *sel) {
     const pea_model_desc &d = m->d;
     pea_plan *plan = const_cast<pea_plan *>(m->plan);
     const int64_t N = plan->N;
@@ -785,8 +785,37 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
     };
 
     // ---- two-step inference schedule, stage 0: aggregate x per channel, then both transforms in one kernel -> T_1
+    // `part` (sharded ranks, pea_model_forward_part): PEA_PART_SOURCES = weight packing, the first-layer aggregation and the
+    // transforms of the first n_owned_first owned rows (the ones other ranks gather from: written into this rank's block of
+    // the exchange buffers as well, so the host can start the all-gather); PEA_PART_REST = the transforms of the other
+    // owned rows (nobody else reads them: they run behind the all-gather); PEA_PART_ALL = both.
     auto run_fused2_stage0 = [&]() -> int {
         Level &L0 = m->levels[0], &L1 = m->levels[1];
+        const int64_t n_first = (sharded && plan->n_owned_first >= 0) ? std::min<int64_t>(plan->n_owned_first, n_own) : n_own;
+        const bool do_first = part != PEA_PART_REST, do_rest = part != PEA_PART_SOURCES;
+        auto run_mlp2 = [&](const Mlp2Launch &ML) -> int {
+            if (part == PEA_PART_ALL) return launch_mlp2(ML, own_rows, n_own, stream);
+            if (do_first) return launch_mlp2(ML, own_rows, n_first, stream);
+            return launch_mlp2(ML, own_rows + n_first, n_own - n_first, stream);
+        };
+        // sharded: a channel's T_1 rows that are gather sources of layer 2 also go into the exchange buffer of its group
+        auto set_exchange = [&](Mlp2Chan &C, const Unit &u1) -> int {
+            C.x_slot = nullptr;
+            C.x_buf = nullptr;
+            C.x_ld = 0;
+            if (!sharded) return PEA_OK;
+            for (const GroupPlan &g : L1.groups) {
+                if (u1.t_col < g.col || u1.t_col >= g.col + g.W) continue;
+                const Relation &R2 = plan->rels[(size_t)g.rel];
+                PEA_REQUIRE(R2.slot_of_node != nullptr && g.xch_ld > 0, PEA_ERR_ARG,
+                            "relation %d has no exchange layout (pea_plan_set_sources)", g.rel);
+                C.x_slot = R2.slot_of_node;
+                C.x_buf = wsf + g.xch_off + (u1.t_col - g.col);
+                C.x_ld = g.xch_ld;
+                return PEA_OK;
+            }
+            PEA_REQUIRE(false, PEA_ERR_ARG, "fused schedule: channel %d has no layer-2 group", u1.p);
+        };
         float *A0 = wsf + L0.off_t;
         Mlp2Launch ML{};
         ML.kind = kind;
@@ -862,11 +891,14 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 C.t1_col = u1->t_col;
                 C.r1_col = u1->o_col;
                 C.deg0 = R.deg0;
+                PEA_TRY(set_exchange(C, *u1));
             }
-            PEA_TRY(launch_mlp2_pack(ML, stream));
-            for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
-                PEA_TRY(launch_aggregate(AGG_MEAN, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
-            return launch_mlp2(ML, own_rows, n_own, stream);
+            if (do_first) {
+                PEA_TRY(launch_mlp2_pack(ML, stream));
+                for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+                    PEA_TRY(launch_aggregate(AGG_MEAN, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+            }
+            return run_mlp2(ML);
         }
         for (size_t ui = 0; ui < L0.units.size(); ++ui) {
             const Unit &u = L0.units[ui];
@@ -884,6 +916,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             C.a0_col = (int)ui * d.emb_dim;
             C.t1_col = u1->t_col;
             C.deg0 = R.deg0;
+            PEA_TRY(set_exchange(C, *u1));
             if (kind == PEA_KIND_GAT) {
                 C.att_dst0 = param(u, 1);   // att_i multiplies the TARGET row
                 C.att_src0 = param(u, 2);   // att_j multiplies the SOURCE row
@@ -933,11 +966,13 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             a.table_rows = (double)R.src_span;
             gs.push_back(a);
         }
-        PEA_TRY(launch_mlp2_pack(ML, stream));
-        const AggMode mode = kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN;
-        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
-            PEA_TRY(launch_aggregate(mode, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
-        return launch_mlp2(ML, own_rows, n_own, stream);
+        if (do_first) {
+            PEA_TRY(launch_mlp2_pack(ML, stream));
+            const AggMode mode = kind == PEA_KIND_GAT ? AGG_GAT : AGG_GCN;
+            for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+                PEA_TRY(launch_aggregate(mode, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        }
+        return run_mlp2(ML);
     };
 
     // Stage k = the work between two exchanges of gather sources (all stages back to back when not sharded):
@@ -945,7 +980,10 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
     // After stage k < last, the gather source of level k+1 is complete on its owner rows (T_{k+1} resp. O_k).
     const int s_beg = stage < 0 ? 0 : stage, s_end = stage < 0 ? n_levels : stage + 1;
     PEA_REQUIRE(s_beg >= 0 && s_end <= n_levels, PEA_ERR_ARG, "forward: stage %d of %d", stage, n_levels);
+    PEA_REQUIRE(part == PEA_PART_ALL || (sharded && stage >= 0), PEA_ERR_ARG, "forward: parts are stages of a sharded plan");
+    const bool splits = m->fused2 && !training;   // only stage 0 of the two-step schedule has a part nobody else reads
     for (int k = s_beg; k < s_end; ++k) {
+        if (part == PEA_PART_REST && !(splits && k == 0)) continue;   // everything ran with PEA_PART_SOURCES
         // the two-step schedule packs everything it reads in its own launch (launch_mlp2_pack)
         if (k == 0 && !(m->fused2 && !training)) PEA_TRY(pack_weights());
         if (m->fused2 && !training) {
@@ -961,7 +999,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         }
         if (k == n_levels - 1 && (out_repr || out_stack))
             PEA_TRY(launch_fuse(N, d.num_channels, d.repr_dim, X, ldX, m->x_col, att, masked, d.fuse_mode, own_rows, n_own,
-                                out_repr, out_stack, stream));
+                                out_repr, out_stack, stream, sel));
     }
     return PEA_OK;
 }
@@ -1045,6 +1083,41 @@ extern "C" int pea_model_forward_stage(pea_model *model, int stage, const float 
     PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward_stage: masked channel %d", masked_channel);
     return model_forward(model, stage, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
                          out_stack, nullptr, 0, 0, (hipStream_t)stream, false);
+}
+
+// One PART of a stage (see run_fused2_stage0) + the optional batch-row selection in the last stage's fusion launch.
+extern "C" int pea_model_forward_part(pea_model *model, int stage, const pea_stage_opts *opts, const float *const *params_host,
+                                      const float *x, const float *att, int masked_channel, void *workspace,
+                                      size_t workspace_bytes, float *out_repr, float *out_stack, void *stream) {
+    PEA_REQUIRE(model && opts && params_host && x && workspace, PEA_ERR_ARG, "forward_part: null argument");
+    PEA_REQUIRE(stage >= 0 && stage < (int)model->levels.size(), PEA_ERR_ARG, "forward_part: stage %d of %d", stage,
+                (int)model->levels.size());
+    PEA_REQUIRE(opts->part == PEA_PART_ALL || opts->part == PEA_PART_SOURCES || opts->part == PEA_PART_REST, PEA_ERR_ARG,
+                "forward_part: part %d", opts->part);
+    PEA_REQUIRE(workspace_bytes >= pea_model_workspace_bytes(model), PEA_ERR_NOMEM, "forward_part: workspace too small");
+    PEA_REQUIRE(masked_channel >= -1 && masked_channel < model->d.num_channels, PEA_ERR_ARG, "forward_part: masked channel %d", masked_channel);
+    FuseSelect sel;
+    const bool last = stage == (int)model->levels.size() - 1;
+    if (opts->n_sel > 0) {
+        PEA_REQUIRE(last && opts->part != PEA_PART_REST, PEA_ERR_ARG, "forward_part: batch rows are selected by the last stage");
+        PEA_REQUIRE(opts->sel_ids && opts->sel_out && opts->err_flag && out_repr, PEA_ERR_ARG, "forward_part: selection needs ids, output, flag, table");
+        sel.ids = opts->sel_ids;
+        sel.id_stride = opts->sel_stride > 0 ? opts->sel_stride : 1;
+        sel.n = opts->n_sel;
+        sel.out = opts->sel_out;
+        sel.err = opts->err_flag;
+        sel.rank = model->plan->shard_rank;
+        sel.world = model->plan->shard_world;
+        sel.tile = model->plan->shard_tile;
+    }
+    return model_forward(model, stage, params_host, x, model->d.emb_dim, att, masked_channel, aligned_ws(workspace), out_repr,
+                         out_stack, nullptr, 0, 0, (hipStream_t)stream, false, opts->part, opts->n_sel > 0 ? &sel : nullptr);
+}
+
+// 1 when stage `stage` writes this rank's rows of the NEXT level's exchange buffers itself (the two-step schedule's fused
+// transform does): the host then only runs the all-gather; 0: the host packs them from the source table first.
+extern "C" int pea_model_stage_fills_exchange(const pea_model *model, int stage) {
+    return model && model->plan->shard_world > 1 && model->fused2 && stage == 0 ? 1 : 0;
 }
 
 // One stage of the TRAINING forward of a sharded model (keeps the softmax statistics and every level buffer the backward

@@ -554,6 +554,13 @@ extern "C" int pea_plan_set_owned_rows(pea_plan *plan, const int32_t *rows, int6
     return PEA_OK;
 }
 
+extern "C" int pea_plan_set_owned_split(pea_plan *plan, int64_t n_first) {
+    PEA_REQUIRE(plan && n_first >= 0 && n_first <= plan->n_owned, PEA_ERR_ARG, "set_owned_split: %lld of %lld owned rows",
+                (long long)n_first, plan ? (long long)plan->n_owned : 0LL);
+    plan->n_owned_first = n_first;
+    return PEA_OK;
+}
+
 extern "C" int pea_plan_set_sources(pea_plan *plan, int relation, const int32_t *slot_of_node, int64_t slots_per_rank,
                                     const int32_t *need_rows, int64_t n_need, void *stream_) {
     using namespace pea;

@@ -98,10 +98,21 @@ class GraphPlan:
         self.layout = ShardLayout(self.num_nodes, *self.shard)
         self.source_layouts = {}
         if self.shard[1] > 1:
-            own = self.layout.owned_rows(self.device).to(torch.int32).contiguous()
-            self.own_rows_i32 = own
-            _lib.check(lib.pea_plan_set_owned_rows(handle, _lib.ptr(own), own.numel(), _lib.current_stream()))
             lays = [self.layout.source_layout(ei) for ei in uniq]
+            # owned rows, the ones OTHER ranks read first: the sources of the relations used at a step >= 1 (the exchanges
+            # between the stages move exactly these rows).  A stage computes them first, the all-gather starts, and the rest
+            # of the stage (rows only this rank reads) runs behind it (pea_model_forward_part).
+            own64 = self.layout.owned_rows(self.device)
+            later = sorted({r for row in self.relation_of for r in row[1:]})
+            is_src = torch.zeros(self.num_nodes, dtype=torch.bool, device=self.device)
+            for r in later:
+                is_src[lays[r].src_nodes] = True
+            first = is_src[own64]
+            own = torch.cat([own64[first], own64[~first]]).to(torch.int32).contiguous()
+            self.own_rows_i32 = own
+            self.n_own_first = int(first.sum().item())
+            _lib.check(lib.pea_plan_set_owned_rows(handle, _lib.ptr(own), own.numel(), _lib.current_stream()))
+            _lib.check(lib.pea_plan_set_owned_split(handle, self.n_own_first))
             # relations with few source nodes (attribute -> item ...) share ONE first-layer row list: own rows + the
             # union of their sources, so their channels' transforms run as one wide job (a few extra rows, same results)
             small = [r for r, lay in enumerate(lays) if lay.src_nodes.numel() * 10 <= own.numel()]
@@ -201,11 +212,16 @@ class PEAEngine:
                     dst = self._wsf[d.dst_offset_bytes // 4:d.dst_offset_bytes // 4 + rows * d.dst_ld].view(rows, d.dst_ld)
                     row.append((d, src, dst, plan.source_layouts[d.relation]))
                 self._exchanges.append(row)
+            # stages whose transform writes this rank's exchange rows itself (no pack launch before the all-gather)
+            self._fills = [bool(lib.pea_model_stage_fills_exchange(handle, k)) for k in range(self.n_stages)]
 
-    def forward(self, layer_params, x, att=None, masked=None, want_stack=False, train=False, gather=True, out=None):
+    def forward(self, layer_params, x, att=None, masked=None, want_stack=False, train=False, gather=True, out=None,
+                select_ids=None):
         """layer_params: list (channel-major, then step) of tuples of tensors in PARAM_SLOTS order
         (a missing bias may be None).  train=True keeps what backward() needs (single GPU).  gather=False (sharded
-        plans only): skip the final all-gather; only the rows this rank owns are defined in the result."""
+        plans only): skip the final all-gather; only the rows this rank owns are defined in the result.  select_ids
+        (sharded, int64 [K]): also returns [K, repr_dim] rows = the fused rows of those nodes this rank owns, zeros for
+        the others (one launch with the fusion; the caller all-reduces them: ShardLayout.reduce_rows)."""
         lib = _lib.load()
         n = self.plan.num_nodes
         if x.shape != (n, self.emb_dim) or x.dtype != torch.float32 or not x.is_cuda:
@@ -258,18 +274,52 @@ class PEAEngine:
         # gather sources of level k+1 are then all-gathered from their owners; after the last stage the fused rows
         # (not the per-metapath stack) are all-gathered: the fusion is row-local under row ownership.
         shard = self.plan.layout
-        stage_fn = lib.pea_model_forward_stage_train if train else lib.pea_model_forward_stage
-        for k in range(self.n_stages):
-            _lib.check(stage_fn(self._h, k, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m,
-                                                   _lib.ptr(self._ws), self.workspace_bytes, _lib.ptr(out),
-                                                   _lib.ptr(stack), _lib.current_stream()))
-            if k + 1 < self.n_stages:
-                for d, src, dst, lay in self._exchanges[k + 1]:
-                    shard.exchange_sources(dst, src, lay, d.src_col, d.width)
+        picked = None
+        if train:
+            if select_ids is not None:
+                raise ValueError('select_ids rides in the inference stages (the training step exchanges stack rows)')
+            for k in range(self.n_stages):
+                _lib.check(lib.pea_model_forward_stage_train(self._h, k, ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m,
+                                                             _lib.ptr(self._ws), self.workspace_bytes, _lib.ptr(out),
+                                                             _lib.ptr(stack), _lib.current_stream()))
+                if k + 1 < self.n_stages:
+                    for d, src, dst, lay in self._exchanges[k + 1]:
+                        shard.exchange_sources(dst, src, lay, d.src_col, d.width)
+        else:
+            # stage k in two parts: (1) everything the exchange after it needs -- the all-gathers of the next level's gather
+            # sources then start (asynchronously under RCCL) -- (2) the rows only this rank reads, behind them; the stream
+            # waits for the collectives just before the next stage.  The last stage's fusion launch also picks the batch's
+            # rows for the loss all-reduce (select_ids).
+            opts = _lib.StageOpts(_lib.PART_ALL, None, 1, 0, None, None)
+            for k in range(self.n_stages):
+                last = k + 1 == self.n_stages
+                opts.part = _lib.PART_ALL if last else _lib.PART_SOURCES
+                if last and select_ids is not None:
+                    ids = select_ids if select_ids.dtype == torch.int64 else select_ids.to(torch.int64)
+                    picked = torch.empty((ids.numel(), self.repr_dim), dtype=torch.float32, device=x.device)
+                    keep.append(ids)
+                    flag = shard._err_flag(x.device)
+                    opts.sel_ids, opts.sel_stride, opts.n_sel = ids.data_ptr(), ids.stride(0) if ids.dim() == 1 else 1, ids.numel()
+                    opts.sel_out, opts.err_flag = picked.data_ptr(), flag.data_ptr()
+                _lib.check(lib.pea_model_forward_part(self._h, k, C.byref(opts), ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m,
+                                                      _lib.ptr(self._ws), self.workspace_bytes, _lib.ptr(out),
+                                                      _lib.ptr(stack), _lib.current_stream()))
+                if last:
+                    break
+                filled = self._fills[k]
+                pending = [shard.exchange_sources(dst, src, lay, d.src_col, d.width, packed=filled, async_op=True)
+                           for d, src, dst, lay in self._exchanges[k + 1]]
+                opts.part = _lib.PART_REST
+                _lib.check(lib.pea_model_forward_part(self._h, k, C.byref(opts), ptrs, _lib.ptr(keep[0]), _lib.ptr(att_t), m,
+                                                      _lib.ptr(self._ws), self.workspace_bytes, _lib.ptr(out),
+                                                      _lib.ptr(stack), _lib.current_stream()))
+                shard.wait_all(pending)
         if gather:
             shard.allgather_rows(out)
             if want_stack:
                 shard.allgather_rows(stack)
+        if select_ids is not None:
+            return out, picked
         return (out, stack) if want_stack else out
 
     def forward_graphed(self, layer_params, x, att=None, masked=None):

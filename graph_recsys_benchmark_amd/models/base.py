@@ -284,11 +284,13 @@ class PEABaseRecsysModel(GraphRecsysModel):
         if not (sharded and self.training) or grad:
             return super().loss(pos_neg_pair_t)
         eng = self._get_engine()
-        part = eng.forward(self._layer_params(), self.x.detach(), getattr(self, 'att', None), gather=False)
-        self.cached_repr, self._repr_partial = part, True
         t = pos_neg_pair_t
         b = t.shape[0]
-        rows = eng.plan.layout.gather_rows(part, t[:, :3].reshape(-1))
+        # the batch's rows ride in the last stage's fusion launch (rows this rank owns, zeros elsewhere), then one all-reduce
+        part, rows = eng.forward(self._layer_params(), self.x.detach(), getattr(self, 'att', None), gather=False,
+                                 select_ids=t[:, :3].reshape(-1))
+        self.cached_repr, self._repr_partial = part, True
+        rows = eng.plan.layout.reduce_rows(rows)
         local = torch.arange(3 * b, dtype=torch.int64, device=t.device).view(b, 3)
         cf_loss = _engine.bpr_score(rows, local, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         if self.entity_aware:

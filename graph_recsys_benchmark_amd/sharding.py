@@ -148,11 +148,16 @@ class ShardLayout:
         return SourceLayout(self, torch.unique(edge_index[0]))
 
     # ---------------------------------------------------------------- collectives
-    def _all_gather_blocks(self, buf, block_rows, group=None):
-        """buf: contiguous [world * block_rows, ld]; block `rank` holds this rank's rows, the others are filled in."""
+    def _all_gather_blocks(self, buf, block_rows, group=None, async_op=False):
+        """buf: contiguous [world * block_rows, ld]; block `rank` holds this rank's rows, the others are filled in.
+        async_op (RCCL only): the collective is issued on RCCL's own stream behind the work already enqueued on the
+        current stream and a work handle is returned; kernels launched afterwards run beside it until wait_all()."""
         if self.world == 1 or block_rows == 0 or self.dry:
-            return
+            return None
         mine = buf[self.rank * block_rows:(self.rank + 1) * block_rows]
+        if async_op and dist.get_backend(group) == 'nccl':
+            send = mine.reshape(-1) if ShardLayout._inplace_ok else mine.reshape(-1).clone()
+            return dist.all_gather_into_tensor(buf.view(-1), send, group=group, async_op=True)
         done = CommTimer.span(buf.device)
         if dist.get_backend(group) == 'nccl':
             # RCCL all-gather IN PLACE: the send block is this rank's slice of the receive buffer (ncclAllGather's
@@ -171,13 +176,28 @@ class ShardLayout:
                     buf[r * block_rows:(r + 1) * block_rows].copy_(p)
         if done is not None:
             done.record()
+        return None
 
-    def exchange_sources(self, xbuf, table, layout, col, width, group=None):
-        """xbuf [world*M, ld] <- all-gather of table[owner's source nodes, col:col+width] (slot order)."""
+    def wait_all(self, works):
+        """The current stream waits for the collectives started with async_op (device-side wait: the host does not
+        block).  The time the stream actually spends waiting -- the part of the exchange that the work issued in between
+        did not cover -- is what CommTimer records for them."""
+        works = [w for w in works if w is not None]
+        if not works:
+            return
+        done = CommTimer.span(torch.cuda.current_device()) if torch.cuda.is_available() else None
+        for w in works:
+            w.wait()
+        if done is not None:
+            done.record()
+
+    def exchange_sources(self, xbuf, table, layout, col, width, group=None, packed=False, async_op=False):
+        """xbuf [world*M, ld] <- all-gather of table[owner's source nodes, col:col+width] (slot order).  packed: this rank's
+        block of xbuf is already filled (the producing kernel wrote the rows straight into their slots)."""
         m = layout.slots_per_rank
         if m == 0:
-            return
-        if layout.own_count:
+            return None
+        if layout.own_count and not packed:
             if table.is_cuda:
                 lib = _hip()
                 lib.check(lib.load().pea_rows_pack(lib.ptr(table), table.stride(0), int(col), int(width),
@@ -185,7 +205,23 @@ class ShardLayout:
                                                    lib.ptr(xbuf[self.rank * m:]), xbuf.stride(0), lib.current_stream()))
             else:
                 xbuf[self.rank * m:self.rank * m + layout.own_count, :width] = table[layout.own_nodes, col:col + width]
-        self._all_gather_blocks(xbuf, m, group)
+        return self._all_gather_blocks(xbuf, m, group, async_op=async_op)
+
+    def reduce_rows(self, rows, group=None):
+        """Sum over the ranks of rows [K, W] in which every rank filled the entries it owns and zeroed the others (x + 0 is
+        exact): the second half of gather_rows for rows a kernel already selected."""
+        if self.world == 1 or self.dry:
+            return rows
+        done = CommTimer.span(rows.device)
+        if dist.get_backend(group) == 'nccl':
+            dist.all_reduce(rows, group=group)
+        else:
+            host = rows.detach().cpu()
+            dist.all_reduce(host, group=group)
+            rows = host.to(rows.device)
+        if done is not None:
+            done.record()
+        return rows
 
     def gather_rows(self, table, ids, group=None):
         """[len(ids), ...] rows table[ids] where every rank only holds the rows it owns: each rank contributes its own

@@ -245,6 +245,30 @@ int pea_model_forward_stage(pea_model *model, int stage, const float *const *par
 int pea_model_forward_stage_train(pea_model *model, int stage, const float *const *params_host, const float *x,
                                   const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
                                   float *out_repr, float *out_stack, void *stream);
+/* A stage in parts, so that the exchange after it can run behind the work that does not feed it (round 3):
+ *   PEA_PART_ALL      the whole stage (what pea_model_forward_stage runs)
+ *   PEA_PART_SOURCES  everything the next exchange needs: the stage restricted to the first n_first owned rows
+ *                     (pea_plan_set_owned_split: the owned rows that are gather sources of a later level come first in
+ *                     the owned-row list) -- where pea_model_stage_fills_exchange() says so, those rows are written into
+ *                     this rank's block of the exchange buffers directly and the host starts the all-gather right away
+ *   PEA_PART_REST     the remaining owned rows (only this rank reads them)
+ * Stages that cannot be split run entirely under PEA_PART_SOURCES and do nothing under PEA_PART_REST.
+ * Last stage: n_sel > 0 adds the batch's rows to the fusion launch: sel_out[k, 0:repr_dim] = the fused row of node
+ * sel_ids[k * sel_stride] when this rank owns it, zeros otherwise (the operand of the loss all-reduce; reference
+ * models/base.py:46-47 reads cached_repr[unids] / [inids]); *err_flag |= 1 for an id outside [0, num_nodes).        */
+enum { PEA_PART_ALL = 0, PEA_PART_SOURCES = 1, PEA_PART_REST = 2 };
+typedef struct pea_stage_opts {
+    int part;
+    const int64_t *sel_ids;
+    int64_t sel_stride, n_sel;
+    float *sel_out;
+    int32_t *err_flag;
+} pea_stage_opts;
+int pea_plan_set_owned_split(pea_plan *plan, int64_t n_first);
+int pea_model_forward_part(pea_model *model, int stage, const pea_stage_opts *opts, const float *const *params_host,
+                           const float *x, const float *att, int masked_channel, void *workspace, size_t workspace_bytes,
+                           float *out_repr, float *out_stack, void *stream);
+int pea_model_stage_fills_exchange(const pea_model *model, int stage);
 int pea_model_num_exchanges(const pea_model *model, int level);
 int pea_model_exchange_desc(const pea_model *model, int level, int k, pea_exchange_desc *out);
 
