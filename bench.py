@@ -588,14 +588,16 @@ def gradient_check(dataset, model, sub_batch, kind):
             row.append(cache[(rel, flipped)])
         edges.append(row)
     want_loss, want, touched = f64_subgraph_loss_and_grads(kind, sd, edges, sub_batch.cpu().numpy())
-    # a tensor's error is measured against ITS largest float64 gradient, floored at 1e-6 of the largest gradient of any
-    # tensor: gradients that vanish analytically (a last-layer att_i: a per-row shift of all logits only matters through the
-    # leaky-relu kink) are sums of O(global) terms that cancel, so their fp32 noise is relative to those terms
+    # a tensor's error is measured against ITS largest float64 gradient plus 5e-3 of the largest gradient of any tensor, so
+    # the tests' bound of 2e-4 reads  err <= 2e-4 * max|tensor| + 1e-6 * max|any|: gradients that vanish analytically are
+    # sums of O(global) terms that cancel (a last-layer att_i: a per-row shift of all logits only matters through the
+    # leaky-relu kink; SAGE layer-2 lin_rel of the channels ending at user rows: with the relu masks of the positive and the
+    # negative score equal, d(pos - neg) / d repr_u is EXACTLY zero), and their fp32 residue is relative to those terms
     g_max = max(float(np.abs(w).max()) for w in want.values())
     worst, worst_name, per = 0.0, None, []
     for k, w in want.items():
         err, scale = float(np.abs(got[k] - w).max()), float(np.abs(w).max())
-        rel_err = err / max(scale, 1e-6 * g_max)
+        rel_err = err / (scale + 5e-3 * g_max)
         per.append((rel_err, k, err, scale))
         if rel_err > worst:
             worst, worst_name = rel_err, k
@@ -610,7 +612,7 @@ def gradient_check(dataset, model, sub_batch, kind):
             'x_rows_in_neighbourhood': int(touched.size), 'x_grad_nonzero_outside_neighbourhood': int(np.count_nonzero(got['x'][outside])),
             'bound_in_tests': 2e-4, 'seconds': round(time.perf_counter() - t0, 1),
             'what': 'every parameter gradient of loss(sub-batch) on the FULL graph vs float64 autograd on the sub-batch\'s '
-                    'complete 2-hop in-neighbourhood (oracle/grad64.py); rel err = max |diff| / max(max |f64| of the tensor, 1e-6 x the largest gradient of any tensor)'}
+                    'complete 2-hop in-neighbourhood (oracle/grad64.py); rel err = max |diff| / (max |f64| of the tensor + 5e-3 x the largest gradient of any tensor)'}
 
 
 def eval_variant(dataset, model, args, timed_region):
