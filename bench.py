@@ -398,11 +398,14 @@ def main():
     lib = _lib.load()
     profile = not args.no_profile
 
+    from graph_recsys_benchmark_amd import engine as _eng
+
     def timed_region(fn, steps, with_events=False):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        _eng.GRAPHS_ENABLED = not with_events     # HIP events around every launch need eager launches (not a graph replay)
         lib.pea_profile_enable(1 if with_events else 0)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -413,6 +416,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         lib.pea_profile_enable(0)
+        _eng.GRAPHS_ENABLED = True
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

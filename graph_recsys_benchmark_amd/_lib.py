@@ -85,6 +85,12 @@ SIGNATURES = {
     'pea_plan_set_owned_split': (_int, [_vp, _i64]),
     'pea_model_forward_part': (_int, [_vp, _int, C.POINTER(StageOpts), C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
     'pea_model_stage_fills_exchange': (_int, [_vp, _int]),
+    'pea_tape_create': (_int, [C.POINTER(_vp)]),
+    'pea_tape_destroy': (_int, [_vp]),
+    'pea_tape_begin': (_int, [_vp]),
+    'pea_tape_end': (_int, [_vp]),
+    'pea_tape_length': (_int, [_vp]),
+    'pea_tape_replay': (_int, [_vp, _vp]),
     'pea_model_num_exchanges': (_int, [_vp, _int]),
     'pea_model_exchange_desc': (_int, [_vp, _int, _int, C.POINTER(ExchangeDesc)]),
     'pea_model_forward_train': (_int, [_vp, C.POINTER(_vp), _vp, _vp, _int, _vp, _sz, _vp, _vp, _vp]),
@@ -161,6 +167,45 @@ def require_device():
     if lib.pea_device_count() <= 0:
         raise PeaError(-5, 'no gfx950 (MI355X) device visible; the HIP path has no CPU fallback')
     return lib
+
+
+class Tape:
+    """A recorded launch sequence (include/peahip.h, pea_tape_*): `with tape.record(): <library calls>` once, then
+    tape.replay() while the pointers those calls were given stay valid."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(load().pea_tape_create(C.byref(self._h)))
+
+    def record(self):
+        return _TapeRecording(self)
+
+    def replay(self):
+        check(load().pea_tape_replay(self._h, current_stream()))
+
+    def __len__(self):
+        return int(load().pea_tape_length(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                load().pea_tape_destroy(h)
+            except Exception:
+                pass
+
+
+class _TapeRecording:
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        check(load().pea_tape_begin(self.tape._h))
+        return self.tape
+
+    def __exit__(self, *exc):
+        load().pea_tape_end(self.tape._h)
+        return False
 
 
 def ptr(t):

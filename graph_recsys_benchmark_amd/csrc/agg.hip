@@ -688,7 +688,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     L.n_long_blocks = blocks;
     if (blocks + sblocks > 0) {
         ProfScope ps(kname<G, MODE>(1), stream, alg_plain + bytes_short, pull_plain + pull_short, table);
-        hipLaunchKernelGGL((agg_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
+        PEA_LAUNCH((agg_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
     // groups with an LDS image of their hottest sources: one persistent launch each
@@ -713,7 +713,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         const double pull = (4.0 * g.W + (MODE == AGG_GCN ? 4.0 : 0.0)) * g.msgs_long * (1.0 - g.hot_frac) + 4.0 * g.msgs_long +
                             (double)grid * (double)lds;
         ProfScope ps(kname<G, MODE>(3), stream, per_msg * g.msgs_long, pull, g.table_rows * 4.0 * g.W);
-        hipLaunchKernelGGL((agg_long_hot_kernel<G, MODE, F4T>), dim3(grid), dim3(kHotBlock), lds, stream, L);
+        PEA_LAUNCH((agg_long_hot_kernel<G, MODE, F4T>), dim3(grid), dim3(kHotBlock), lds, stream, L);
         PEA_HIP(hipGetLastError());
     }
     // hub merge
@@ -729,7 +729,7 @@ int launch_for_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     L.blk_start[L.n_groups] = blocks;
     if (blocks > 0) {
         ProfScope ps(kname<G, MODE>(2), stream, 0.0);
-        hipLaunchKernelGGL((agg_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+        PEA_LAUNCH((agg_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
     return PEA_OK;
@@ -783,7 +783,7 @@ int launch_fat(const AggLaunch &base, const int *sel, int n_sel, hipStream_t str
     L.blk_start[L.n_groups] = blocks;
     if (blocks <= 0) return PEA_OK;
     ProfScope ps(fat_name<MODE>(G), stream, alg, pull, table);
-    hipLaunchKernelGGL((agg_long_fat_kernel<G, MODE, HL, V4>), dim3(blocks), dim3(kBlock), 0, stream, L);
+    PEA_LAUNCH((agg_long_fat_kernel<G, MODE, HL, V4>), dim3(blocks), dim3(kBlock), 0, stream, L);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }

@@ -406,7 +406,7 @@ int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         L.n_long_blocks = blocks;
         if (blocks + sblocks > 0) {
             ProfScope ps(nm, stream, pulled, pulled, table);
-            hipLaunchKernelGGL((bwd_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
+            PEA_LAUNCH((bwd_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
             PEA_HIP(hipGetLastError());
         }
     }
@@ -423,7 +423,7 @@ int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         L.blk_start[L.n_groups] = blocks;
         if (blocks > 0) {
             ProfScope ps(MODE == AGG_GAT_BWD_D ? "gat_bwd_dst_merge" : "gat_bwd_src_merge", stream, 0.0);
-            hipLaunchKernelGGL((bwd_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
+            PEA_LAUNCH((bwd_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
             PEA_HIP(hipGetLastError());
         }
     }
@@ -604,7 +604,7 @@ template <bool MP, bool TW>
 static void colsum_dispatch(int T, size_t lds_bytes, hipStream_t stream, const RowMap &rows, int W, int F, int C, const float *A,
                             int lda, const float *S0, const float *S1, int lds, float *part, size_t part_stride) {
 #define PEA_COLSUM(TT)                                                                                                        \
-    hipLaunchKernelGGL((colsum_stage1<MP, TW, TT>), dim3(kColsumParts), dim3(256), lds_bytes, stream, rows, W, F, C, A, lda, S0, \
+    PEA_LAUNCH((colsum_stage1<MP, TW, TT>), dim3(kColsumParts), dim3(256), lds_bytes, stream, rows, W, F, C, A, lda, S0, \
                        S1, lds, part, part_stride)
     if (T == 1) PEA_COLSUM(1);
     else if (T == 2) PEA_COLSUM(2);
@@ -633,9 +633,9 @@ int launch_colsum2(const RowMap &rows, int W, int F, const float *A, int lda, co
     else if (mapped) colsum_dispatch<true, false>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
     else if (two) colsum_dispatch<false, true>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
     else colsum_dispatch<false, false>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
-    hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W, part, scale, out0);
+    PEA_LAUNCH(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W, part, scale, out0);
     if (two)
-        hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W,
+        PEA_LAUNCH(colsum_stage2, dim3((unsigned)((W + 15) / 16)), dim3(256), 0, stream, kColsumParts, W,
                            part + part_stride, scale, out1);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
@@ -650,7 +650,7 @@ int launch_relu_mask(const RowMap &rows, int W, float *G, int ldg, const float *
     if (W <= 0 || rows.n <= 0) return PEA_OK;
     ProfScope ps("relu_mask", stream, 0.0);
     const int64_t total = rows.n * (W / 4);
-    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rows, W / 4, G, ldg, O, ldo);
+    PEA_LAUNCH(relu_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rows, W / 4, G, ldg, O, ldo);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }

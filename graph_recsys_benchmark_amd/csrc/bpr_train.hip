@@ -405,13 +405,13 @@ extern "C" int pea_rows_scatter_sum(int64_t n, const int64_t *ids, const float *
         attr_set = true;
     }
     ProfScope ps("scatter_sum", stream, (double)n * P * R * 8.0);
-    hipLaunchKernelGGL(sort_ids_kernel, dim3(1), dim3(kSortThreads), (size_t)n * 8, stream, (int)n, num_rows, ids, sorted);
+    PEA_LAUNCH(sort_ids_kernel, dim3(1), dim3(kSortThreads), (size_t)n * 8, stream, (int)n, num_rows, ids, sorted);
     PEA_HIP(hipGetLastError());
     const int blocks = (int)((n + 3) / 4);
     if (P * R > 256) {
-        hipLaunchKernelGGL(scatter_runs_kernel<4>, dim3(blocks), dim3(256), 0, stream, (int)n, sorted, src, ld_src, P * R, R, cols, dst, ld_dst);
+        PEA_LAUNCH(scatter_runs_kernel<4>, dim3(blocks), dim3(256), 0, stream, (int)n, sorted, src, ld_src, P * R, R, cols, dst, ld_dst);
     } else {
-        hipLaunchKernelGGL(scatter_runs_kernel<1>, dim3(blocks), dim3(256), 0, stream, (int)n, sorted, src, ld_src, P * R, R, cols, dst, ld_dst);
+        PEA_LAUNCH(scatter_runs_kernel<1>, dim3(blocks), dim3(256), 0, stream, (int)n, sorted, src, ld_src, P * R, R, cols, dst, ld_dst);
     }
     PEA_HIP(hipGetLastError());
     return PEA_OK;
@@ -446,7 +446,7 @@ extern "C" int pea_bpr_train(int64_t B, int P, int R, const float *rows, int64_t
         ProfScope ps("bpr_train", stream, (double)B * 3.0 * P * R * 8.0);
 #define PEA_BT_CASE(r4)                                                                                               \
     case r4:                                                                                                          \
-        hipLaunchKernelGGL(bpr_train_kernel<r4>, dim3(blocks), dim3(kTB), sh, stream, B, P, rows, ld_rows, att, fc1_w, \
+        PEA_LAUNCH(bpr_train_kernel<r4>, dim3(blocks), dim3(kTB), sh, stream, B, P, rows, ld_rows, att, fc1_w, \
                            fc1_b, fc2_w, fc2_b, grad_rows, dhx, zx, dsc, P4, sums);                                   \
         break;
         switch (R / 4) {
@@ -458,13 +458,13 @@ extern "C" int pea_bpr_train(int64_t B, int P, int R, const float *rows, int64_t
             PEA_BT_CASE(6)
             PEA_BT_CASE(7)
             default:
-                hipLaunchKernelGGL(bpr_train_kernel<8>, dim3(blocks), dim3(kTB), sh, stream, B, P, rows, ld_rows, att,
+                PEA_LAUNCH(bpr_train_kernel<8>, dim3(blocks), dim3(kTB), sh, stream, B, P, rows, ld_rows, att,
                                    fc1_w, fc1_b, fc2_w, fc2_b, grad_rows, dhx, zx, dsc, P4, sums);
         }
 #undef PEA_BT_CASE
         PEA_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(bpr_train_final_kernel, dim3(1), dim3(256), 0, stream, blocks, sums, out_loss);
+    PEA_LAUNCH(bpr_train_final_kernel, dim3(1), dim3(256), 0, stream, blocks, sums, out_loss);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }

@@ -186,14 +186,14 @@ int launch_gw(const GwBatch &Jb, const RowMap &rows, float *partial, double byte
             full = Jb.j[q].ma == 64 && Jb.j[q].nb == 64 && Jb.j[q].lda % 4 == 0 && Jb.j[q].ldb % 4 == 0 &&
                    (reinterpret_cast<uintptr_t>(Jb.j[q].a) | reinterpret_cast<uintptr_t>(Jb.j[q].b)) % 16 == 0;
         if (full) {
-            hipLaunchKernelGGL(gw_stage1_lds, dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
+            PEA_LAUNCH(gw_stage1_lds, dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
         } else {
-            hipLaunchKernelGGL((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
+            PEA_LAUNCH((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
         }
         PEA_HIP(hipGetLastError());
     }
     ProfScope ps("grad_weight_sum", stream);
-    hipLaunchKernelGGL((gw_stage2<MT, NT>), dim3(MT * NT, (unsigned)Jb.n), dim3(256), 0, stream, Jb, partial);
+    PEA_LAUNCH((gw_stage2<MT, NT>), dim3(MT * NT, (unsigned)Jb.n), dim3(256), 0, stream, Jb, partial);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }

@@ -142,12 +142,12 @@ extern "C" int pea_entity_reg(int64_t B, int emb_dim, int64_t num_nodes, const f
     const int blocks = (int)((B + rpb - 1) / rpb);
     int *err = (int *)workspace;
     float *bi = (float *)workspace + 4, *bu = bi + blocks;
-    PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
+    PEA_MEMSET_ASYNC(err, 0, sizeof(int), stream);
     ProfScope ps("entity_reg", stream, (double)B * (72.0 + 24.0 * emb_dim));
     if (blocks > 0) {
 #define PEA_ENT_CASE(g)                                                                                                   \
     case g:                                                                                                               \
-        hipLaunchKernelGGL(entity_kernel<g>, dim3(blocks), dim3(256), 0, stream, B, emb_dim, num_nodes, x, ldx, batch,   \
+        PEA_LAUNCH(entity_kernel<g>, dim3(blocks), dim3(256), 0, stream, B, emb_dim, num_nodes, x, ldx, batch,   \
                            batch_stride, bi, bu, grad_rows, err);                                                         \
         break;
         switch (256 / rpb) {
@@ -156,13 +156,13 @@ extern "C" int pea_entity_reg(int64_t B, int emb_dim, int64_t num_nodes, const f
             PEA_ENT_CASE(16)
             PEA_ENT_CASE(32)
             default:
-                hipLaunchKernelGGL(entity_kernel<64>, dim3(blocks), dim3(256), 0, stream, B, emb_dim, num_nodes, x, ldx, batch,
+                PEA_LAUNCH(entity_kernel<64>, dim3(blocks), dim3(256), 0, stream, B, emb_dim, num_nodes, x, ldx, batch,
                                    batch_stride, bi, bu, grad_rows, err);
         }
 #undef PEA_ENT_CASE
         PEA_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(entity_final_kernel, dim3(1), dim3(256), 0, stream, blocks, bi, bu, err, out_reg);
+    PEA_LAUNCH(entity_final_kernel, dim3(1), dim3(256), 0, stream, blocks, bi, bu, err, out_reg);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }

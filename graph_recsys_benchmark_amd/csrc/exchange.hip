@@ -111,7 +111,7 @@ extern "C" int pea_rows_pack(const float *table, int64_t ld, int col, int width,
     PEA_TRY(check_w(width, dst_ld, "rows_pack"));
     ProfScope ps("xchg_pack", stream, 8.0 * (double)n * width);
     const int w4 = width / 4;
-    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n * w4 + 255) / 256)), dim3(256), 0, stream, n, w4, table + col, ld,
+    PEA_LAUNCH(pack_rows_kernel, dim3((unsigned)((n * w4 + 255) / 256)), dim3(256), 0, stream, n, w4, table + col, ld,
                        nodes, dst, dst_ld);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
@@ -127,7 +127,7 @@ extern "C" int pea_rows_unpack(const float *src, int64_t src_ld, const int32_t *
     PEA_TRY(check_w(width, src_ld, "rows_unpack"));
     ProfScope ps("xchg_unpack", stream, 8.0 * (double)n * width);
     const int w4 = width / 4;
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((n * w4 + 255) / 256)), dim3(256), 0, stream, n, w4, src, src_ld,
+    PEA_LAUNCH(unpack_rows_kernel, dim3((unsigned)((n * w4 + 255) / 256)), dim3(256), 0, stream, n, w4, src, src_ld,
                        src_rows, nodes, table + col, ld);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
@@ -144,7 +144,7 @@ extern "C" int pea_rows_select_owned(const float *table, int64_t ld, int width, 
     PEA_TRY(check_w(width, ld, "rows_select_owned"));
     ProfScope ps("xchg_select", stream, 8.0 * (double)n * width);
     const int w4 = width / 4;
-    hipLaunchKernelGGL(select_owned_kernel, dim3((unsigned)((n * w4 + 255) / 256)), dim3(256), 0, stream, n, w4, num_nodes, table,
+    PEA_LAUNCH(select_owned_kernel, dim3((unsigned)((n * w4 + 255) / 256)), dim3(256), 0, stream, n, w4, num_nodes, table,
                        ld, ids, id_stride, rank, world, tile, out, err_flag);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
@@ -180,8 +180,8 @@ static int xchg_batch(bool pack, int n_jobs, const pea_xchg_job *jobs, float *bu
         if (B.total == 0) continue;
         ProfScope ps(pack ? "xchg_pack" : "xchg_unpack", stream, bytes);
         const unsigned blocks = (unsigned)((B.total + 255) / 256);
-        if (pack) hipLaunchKernelGGL(xchg_batch_kernel<true>, dim3(blocks), dim3(256), 0, stream, B, buf, rank_stride);
-        else hipLaunchKernelGGL(xchg_batch_kernel<false>, dim3(blocks), dim3(256), 0, stream, B, buf, rank_stride);
+        if (pack) PEA_LAUNCH(xchg_batch_kernel<true>, dim3(blocks), dim3(256), 0, stream, B, buf, rank_stride);
+        else PEA_LAUNCH(xchg_batch_kernel<false>, dim3(blocks), dim3(256), 0, stream, B, buf, rank_stride);
         PEA_HIP(hipGetLastError());
     }
     return PEA_OK;

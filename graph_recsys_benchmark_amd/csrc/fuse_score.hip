@@ -315,7 +315,7 @@ int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const C
     const unsigned blocks = fuse_blocks + (unsigned)((sel.n + (256 / G) - 1) / (256 / G));
 #define PEA_FUSE_CASE(g)                                                                                       \
     case g:                                                                                                    \
-        hipLaunchKernelGGL(fuse_kernel<g>, dim3(blocks), dim3(256), 0, stream, n_rows, rows, P, R, stack, ld, \
+        PEA_LAUNCH(fuse_kernel<g>, dim3(blocks), dim3(256), 0, stream, n_rows, rows, P, R, stack, ld, \
                            col_of_channel, att, masked, mode, out, out_stack, fuse_blocks, sel, N);            \
         break;
     switch (G) {
@@ -326,7 +326,7 @@ int launch_fuse(int64_t N, int P, int R, const float *stack, int64_t ld, const C
         PEA_FUSE_CASE(16)
         PEA_FUSE_CASE(32)
         default:
-            hipLaunchKernelGGL(fuse_kernel<64>, dim3(blocks), dim3(256), 0, stream, n_rows, rows, P, R, stack, ld,
+            PEA_LAUNCH(fuse_kernel<64>, dim3(blocks), dim3(256), 0, stream, n_rows, rows, P, R, stack, ld,
                                col_of_channel, att, masked, mode, out, out_stack, fuse_blocks, sel, N);
     }
 #undef PEA_FUSE_CASE
@@ -382,15 +382,15 @@ extern "C" int pea_bpr_score(int64_t B, int R, int64_t num_nodes, const float *r
     const int blocks = (int)((B + 255) / 256);
     int *err = (int *)workspace;
     float *sums = (float *)workspace + 4;
-    PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
+    PEA_MEMSET_ASYNC(err, 0, sizeof(int), stream);
     const size_t sh = (size_t)(2 * R * R + 2 * R) * sizeof(float);
     pea::ProfScope ps("bpr_score", stream, (double)B * (12.0 + 12.0 * R + 4.0));
     if (blocks > 0) {
-        hipLaunchKernelGGL(pea::bpr_kernel, dim3(blocks), dim3(256), sh, stream, B, R, num_nodes, repr, triples,
+        PEA_LAUNCH(pea::bpr_kernel, dim3(blocks), dim3(256), sh, stream, B, R, num_nodes, repr, triples,
                            triple_stride, fc1_w, fc1_b, fc2_w, fc2_b, pos, neg, sums, err);
         PEA_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(pea::bpr_final_kernel, dim3(1), dim3(256), 0, stream, blocks, sums, err, loss);
+    PEA_LAUNCH(pea::bpr_final_kernel, dim3(1), dim3(256), 0, stream, blocks, sums, err, loss);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
@@ -404,9 +404,9 @@ extern "C" int pea_predict(int64_t B, int R, int64_t num_nodes, const float *rep
     if (B == 0) return PEA_OK;
     int *err = err_flag_for_current_device();
     PEA_REQUIRE(err != nullptr, PEA_ERR_HIP, "predict: no error-flag buffer on this device");
-    PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
+    PEA_MEMSET_ASYNC(err, 0, sizeof(int), stream);
     const size_t sh = (size_t)(2 * R * R + 2 * R) * sizeof(float);
-    hipLaunchKernelGGL(pea::predict_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), sh, stream, B, R, num_nodes,
+    PEA_LAUNCH(pea::predict_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), sh, stream, B, R, num_nodes,
                        repr, unids, inids, fc1_w, fc1_b, fc2_w, fc2_b, pred, err);
     int rc = hipGetLastError() == hipSuccess ? PEA_OK : PEA_ERR_HIP;
     if (rc == PEA_OK) rc = read_err_flag(err, stream, "predict");
@@ -423,9 +423,9 @@ extern "C" int pea_rank_eval(int64_t U, int C, int R, int64_t num_nodes, const f
     if (U == 0) return PEA_OK;
     int *err = err_flag_for_current_device();
     PEA_REQUIRE(err != nullptr, PEA_ERR_HIP, "rank_eval: no error-flag buffer on this device");
-    PEA_HIP(hipMemsetAsync(err, 0, sizeof(int), stream));
+    PEA_MEMSET_ASYNC(err, 0, sizeof(int), stream);
     const size_t sh = (size_t)(2 * R * R + 2 * R) * sizeof(float);
-    hipLaunchKernelGGL(pea::rank_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), sh, stream, U, C, R, num_nodes, repr,
+    PEA_LAUNCH(pea::rank_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), sh, stream, U, C, R, num_nodes, repr,
                        unids, cand, fc1_w, fc1_b, fc2_w, fc2_b, scores, rank, auc, loss, err);
     int rc = hipGetLastError() == hipSuccess ? PEA_OK : PEA_ERR_HIP;
     if (rc == PEA_OK) rc = read_err_flag(err, stream, "rank_eval");

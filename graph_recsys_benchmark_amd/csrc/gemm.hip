@@ -716,7 +716,7 @@ static int launch_skinny_v(const GemmBatch &Bt, const SkinnyArgs &Sa, size_t lds
         attr_set = true;
     }
     ProfScope ps("gemm_mfma_narrow", stream, bytes);
-    hipLaunchKernelGGL((gemm_skinny_kernel<KQ, LISTED>), dim3((unsigned)grid), dim3(512), lds, stream, Bt, Sa, rows, n_rows);
+    PEA_LAUNCH((gemm_skinny_kernel<KQ, LISTED>), dim3((unsigned)grid), dim3(512), lds, stream, Bt, Sa, rows, n_rows);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
@@ -832,7 +832,7 @@ int launch_persist_v(const GemmBatch &Bt, const PersistArgs &Pa, size_t lds, int
     }
     constexpr int NT = KH > 32 ? 512 : 1024;
     ProfScope ps(Bt.n == 1 ? "gemm_mfma_shared" : "gemm_mfma_batch", stream, bytes);
-    hipLaunchKernelGGL((gemm_persist_kernel<KH, LISTED>), dim3((unsigned)grid), dim3(NT), lds, stream, Bt, Pa, rows, n_rows);
+    PEA_LAUNCH((gemm_persist_kernel<KH, LISTED>), dim3((unsigned)grid), dim3(NT), lds, stream, Bt, Pa, rows, n_rows);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
@@ -992,8 +992,8 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                         if (!n_cu_deep && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_deep = prop.multiProcessorCount;
                         const int64_t tiles = (max_rows + 31) / 32;
                         dim3 grid_r((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu_deep > 0 ? n_cu_deep : 256, (tiles + 15) / 16)), (unsigned)Bt.n);
-                        if (nct_r == 1) hipLaunchKernelGGL(gemm_deep_resident_kernel<1>, grid_r, dim3(1024), lds_res, stream, Bt, rows, n_rows);
-                        else hipLaunchKernelGGL(gemm_deep_resident_kernel<2>, grid_r, dim3(1024), lds_res, stream, Bt, rows, n_rows);
+                        if (nct_r == 1) PEA_LAUNCH(gemm_deep_resident_kernel<1>, grid_r, dim3(1024), lds_res, stream, Bt, rows, n_rows);
+                        else PEA_LAUNCH(gemm_deep_resident_kernel<2>, grid_r, dim3(1024), lds_res, stream, Bt, rows, n_rows);
                     } else if (max_out <= 128 && !(env && atoi(env) != 0)) {
                         const int nct = max_out <= 32 ? 1 : max_out <= 64 ? 2 : 4;
                         const size_t lds_deep = (size_t)2 * 128 * 32 * nct * sizeof(float);
@@ -1005,11 +1005,11 @@ int launch_gemm_batch(const GemmJob *jobs_in, int n_jobs_in, const int *rows, in
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 * 4);
                             attr_set = true;
                         }
-                        if (nct == 1) hipLaunchKernelGGL(gemm_deep_kernel<1>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
-                        else if (nct == 2) hipLaunchKernelGGL(gemm_deep_kernel<2>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
-                        else hipLaunchKernelGGL(gemm_deep_kernel<4>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
+                        if (nct == 1) PEA_LAUNCH(gemm_deep_kernel<1>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
+                        else if (nct == 2) PEA_LAUNCH(gemm_deep_kernel<2>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
+                        else PEA_LAUNCH(gemm_deep_kernel<4>, grid, dim3(256), lds_deep, stream, Bt, rows, n_rows);
                     } else {
-                        hipLaunchKernelGGL(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows);
+                        PEA_LAUNCH(gemm_mfma_kernel<64>, grid, dim3(256), 0, stream, Bt, rows, n_rows);
                     }
                     if (hipGetLastError() != hipSuccess) rc = PEA_ERR_HIP;
                 }
@@ -1045,7 +1045,7 @@ int launch_pack(const PackJob *jobs, int n_jobs, hipStream_t stream) {
         L.n = n_jobs - base < 24 ? n_jobs - base : 24;
         for (int i = 0; i < L.n; ++i) L.j[i] = jobs[base + i];
         ProfScope ps("pack_weights", stream);
-        hipLaunchKernelGGL(pack_kernel, dim3(L.n), dim3(256), 0, stream, L);
+        PEA_LAUNCH(pack_kernel, dim3(L.n), dim3(256), 0, stream, L);
         PEA_HIP(hipGetLastError());
     }
     return PEA_OK;

@@ -369,7 +369,7 @@ int launch_mlp2_pack(const Mlp2Launch &L, hipStream_t stream) {
     ProfScope ps("pack_weights2", stream);
     const int kt = (L.kind == PEA_KIND_SAGE ? 2 : 1) * L.emb / 8, ht = L.hid / 32;
     const int split = std::max(4, std::min(32, mlp2_image_floats(kt, ht) / 2048));
-    hipLaunchKernelGGL(mlp2_pack_kernel, dim3((unsigned)(L.n * split)), dim3(256), 0, stream, L);
+    PEA_LAUNCH(mlp2_pack_kernel, dim3((unsigned)(L.n * split)), dim3(256), 0, stream, L);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
@@ -415,9 +415,9 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
     const int grid = blocks;
     ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out * (SAGE ? 2 : 1)));
     if (SAGE) {
-        hipLaunchKernelGGL((mlp2_sage_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
+        PEA_LAUNCH((mlp2_sage_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     } else {
-        hipLaunchKernelGGL((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
+        PEA_LAUNCH((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     }
     PEA_HIP(hipGetLastError());
     return PEA_OK;

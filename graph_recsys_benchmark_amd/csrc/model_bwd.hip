@@ -28,12 +28,12 @@ int ensure_sage_arrays(pea_plan *plan, int rel, hipStream_t stream) {
     const int64_t N = plan->N;
     if (!plan->ones) {
         PEA_HIP(hipMalloc((void **)&plan->ones, (size_t)N * sizeof(float)));
-        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, 1.0f, plan->ones);
+        PEA_LAUNCH(fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, 1.0f, plan->ones);
     }
     Relation &R = plan->rels[(size_t)rel];
     if (!R.invdeg) {
         PEA_HIP(hipMalloc((void **)&R.invdeg, (size_t)N * sizeof(float)));
-        hipLaunchKernelGGL(invdeg_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, R.rowptr, R.invdeg);
+        PEA_LAUNCH(invdeg_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, R.rowptr, R.invdeg);
     }
     PEA_HIP(hipGetLastError());
     return PEA_OK;
@@ -135,7 +135,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
     const bool part_b = phase == 2 || !sharded;   // gathers over the reversed relation, reductions of their results
     if (d.kind == PEA_KIND_GAT && part_a) {
         // rows whose softmax is their self loop alone are skipped by the D pass (alpha = 1, d z = 0): their d a_dst reads 0
-        PEA_HIP(hipMemsetAsync(wsf + L.off_dad, 0, (size_t)N * (size_t)L.ld_k * sizeof(float), stream));
+        PEA_MEMSET_ASYNC(wsf + L.off_dad, 0, (size_t)N * (size_t)L.ld_k * sizeof(float), stream);
     }
     // relu between the steps (reference models/base.py:138): the output gradient of the channels that continue is masked
     // in place, one launch per run of groups whose columns are contiguous in dO (a 2-step model's first level: the whole row)

@@ -79,9 +79,9 @@ extern "C" int pea_sample_negatives(int64_t n_pos, int k, const int64_t *pos_u, 
     if (n_pos == 0) return PEA_OK;
     const long long total = (long long)n_pos * k;
     hipStream_t st = (hipStream_t)stream;
-    PEA_HIP(hipMemsetAsync(exhausted, 0, sizeof(int), st));
+    PEA_MEMSET_ASYNC(exhausted, 0, sizeof(int), st);
     ProfScope ps("sample_negatives", st);
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n_pos, k,
+    PEA_LAUNCH(sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n_pos, k,
                        reinterpret_cast<const long long *>(pos_u), reinterpret_cast<const long long *>(pos_i),
                        (long long)item_lo, (long long)num_items, reinterpret_cast<const long long *>(seen_keys_sorted),
                        (long long)n_keys, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), (unsigned)offset,

@@ -14,6 +14,14 @@ from . import _lib
 from .sharding import ShardLayout
 
 KINDS = {'gat': _lib.KIND_GAT, 'gcn': _lib.KIND_GCN, 'sage': _lib.KIND_SAGE}
+GRAPHS_ENABLED = True     # bench.py clears it for its per-kernel HIP-event pass (events are not part of a captured graph)
+
+
+def _shard_replay_mode():
+    import os
+    mode = os.environ.get('PEA_SHARD_REPLAY', 'tape')
+    return mode if mode in ('tape', 'graph', 'eager') else 'tape'
+
 # parameter slots per conv layer, in the order pea_model_forward expects (include/peahip.h)
 PARAM_SLOTS = {
     'gat': ('lin.weight', 'att_i', 'att_j', 'bias'),
@@ -321,6 +329,127 @@ class PEAEngine:
         if select_ids is not None:
             return out, picked
         return (out, stack) if want_stack else out
+
+    # ------------------------------------------------------------------ sharded loss step, launches replayed from hipGraphs
+    def _param_table(self, layer_params):
+        sig = tuple(None if t is None else t.data_ptr() for lp in layer_params for t in lp)
+        cached = getattr(self, '_ptr_cache', None)
+        if cached is None or cached[0] != sig:
+            return None, sig
+        return cached[1], sig
+
+    def sharded_loss(self, layer_params, x, att, triples, fc1_w, fc1_b, fc2_w, fc2_b):
+        """One rank's share of  loss = model.loss(batch)  without autograd (reference models/base.py:43-48 in training
+        mode: full-graph forward, then the BPR term of the batch) on a sharded plan, with every launch sequence between two
+        collectives recorded ONCE on a launch tape (csrc/tape.hip; or captured into a hipGraph, PEA_SHARD_REPLAY=graph) and
+        replayed while the argument pointers stay the same (parameters and
+        x are updated in place by an optimizer; the batch is copied into a static id buffer):
+
+            graph[stage 0, rows other ranks read] -> all-gather(s) of the next level's sources, asynchronous
+            graph[stage 0, remaining rows]        -> stream waits for the all-gathers
+            graph[last stage + fusion + the batch's rows] -> all-reduce of [3B, repr_dim] -> graph[scorer + BPR sum]
+
+        A rank of 8 on the 25m-shaped graph issues ~10 launches of 10-90 us each; enqueueing them one by one through
+        ctypes took as long as running them.  Returns (loss, fused rows of this rank [N, repr_dim]); both are static
+        buffers that the next call overwrites (the loss is cloned).  PEA_SHARD_REPLAY=eager or GRAPHS_ENABLED = False (bench.py's
+        per-kernel event pass): the same sequence, eager."""
+        lib = _lib.load()
+        shard = self.plan.layout
+        n, b = self.plan.num_nodes, triples.shape[0]
+        dev = x.device
+        st = getattr(self, '_sl', None)
+        if st is None or st['b'] != b:
+            st = self._sl = {
+                'b': b, 'ids': torch.empty(3 * b, dtype=torch.int64, device=dev),
+                'out': torch.empty((n, self.repr_dim), dtype=torch.float32, device=dev),
+                'picked': torch.empty((3 * b, self.repr_dim), dtype=torch.float32, device=dev),
+                'local': torch.arange(3 * b, dtype=torch.int64, device=dev).view(b, 3),
+                'loss': torch.empty((), dtype=torch.float32, device=dev),
+                'ws': torch.zeros(int(lib.pea_bpr_workspace_bytes(b)), dtype=torch.uint8, device=dev),
+                'key': None, 'graphs': None}
+            # (the scorer reads local positions 0 .. 3B-1 of `picked`; node ids are validated where they are used, in the
+            # fusion launch's row selection: ShardLayout._err_flag, checked by check_pending_errors like a bad BPR triple)
+        t3 = triples[:, :3]
+        st['ids'].view(b, 3).copy_(t3)
+        att_t = att.detach().reshape(self.P, self.repr_dim) if self.channel_aggr == 'att' else None
+        if att_t is not None and not att_t.is_contiguous():
+            att_t = att_t.contiguous()
+        fc = [t.detach() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
+        if any(not t.is_contiguous() for t in fc):
+            fc = [t.contiguous() for t in fc]
+        ptrs, sig = self._param_table(layer_params)
+        if ptrs is None:         # first call / a parameter moved: the eager forward validates and rebuilds the pointer table
+            self.forward(layer_params, x, att=att, gather=False, out=st['out'])
+            ptrs, sig = self._param_table(layer_params)
+            if ptrs is None:
+                raise ValueError('sharded_loss needs contiguous float32 parameters')
+            st['key'] = None
+        xd = x.detach()
+        flag = shard._err_flag(dev)
+        stream = _lib.current_stream
+
+        def part(k, which, select):
+            opts = _lib.StageOpts(which, None, 1, 0, None, None)
+            if select:
+                opts.sel_ids, opts.sel_stride, opts.n_sel = st['ids'].data_ptr(), 1, 3 * b
+                opts.sel_out, opts.err_flag = st['picked'].data_ptr(), flag.data_ptr()
+            _lib.check(lib.pea_model_forward_part(self._h, k, C.byref(opts), ptrs, _lib.ptr(xd), _lib.ptr(att_t), -1,
+                                                  _lib.ptr(self._ws), self.workspace_bytes, _lib.ptr(st['out']), None, stream()))
+
+        def score():
+            _lib.check(lib.pea_bpr_score(b, self.repr_dim, 3 * b, _lib.ptr(st['picked']), _lib.ptr(st['local']), 3,
+                                         _lib.ptr(fc[0]), _lib.ptr(fc[1]), _lib.ptr(fc[2]), _lib.ptr(fc[3]), None, None,
+                                         _lib.ptr(st['loss']), _lib.ptr(st['ws']), st['ws'].numel(), stream()))
+
+        last = self.n_stages - 1
+        steps = []                                   # (name, callable) of every launch sequence between two collectives
+        for k in range(self.n_stages):
+            if k < last:
+                steps.append((('src', k), lambda k=k: part(k, _lib.PART_SOURCES, False)))
+                steps.append((('rest', k), lambda k=k: part(k, _lib.PART_REST, False)))
+            else:
+                steps.append((('last', k), lambda k=k: part(k, _lib.PART_ALL, True)))
+        steps.append((('score', 0), score))
+        # replay mode: 'tape' (default: the library's launch tape, csrc/tape.hip), 'graph' (hipGraphs: slower on the GPU
+        # side, kept for comparison), 'eager' (PEA_SHARD_REPLAY=eager, or while bench.py times every launch with events)
+        mode = _shard_replay_mode() if GRAPHS_ENABLED else 'eager'
+        key = (mode, sig, xd.data_ptr(), None if att_t is None else att_t.data_ptr(), tuple(t.data_ptr() for t in fc),
+               self._ws.data_ptr())
+        if mode != 'eager' and st['key'] != key:
+            for _, fn in steps:                      # warm-up on the real stream: lazy plan state (GCN norms ...) is built here
+                fn()
+            torch.cuda.synchronize()
+            recs = {}
+            for name, fn in steps:
+                if mode == 'graph':
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        fn()
+                else:
+                    g = _lib.Tape()
+                    with g.record():
+                        fn()
+                recs[name] = g
+            st['key'], st['graphs'] = key, recs
+        run = (lambda name, fn: fn()) if mode == 'eager' else (lambda name, fn: st['graphs'][name].replay())
+        it = iter(steps)
+        for k in range(self.n_stages):
+            if k < last:
+                name, fn = next(it)
+                run(name, fn)
+                filled = self._fills[k]
+                pending = [shard.exchange_sources(dst, src, lay, d.src_col, d.width, packed=filled, async_op=True)
+                           for d, src, dst, lay in self._exchanges[k + 1]]
+                name, fn = next(it)
+                run(name, fn)
+                shard.wait_all(pending)
+            else:
+                name, fn = next(it)
+                run(name, fn)
+        shard.reduce_rows_(st['picked'])
+        name, fn = next(it)
+        run(name, fn)
+        return st['loss'].clone(), st['out']
 
     def forward_graphed(self, layer_params, x, att=None, masked=None):
         """forward() with the launches of the schedule captured ONCE into a hipGraph and replayed while the argument

@@ -285,14 +285,13 @@ class PEABaseRecsysModel(GraphRecsysModel):
             return super().loss(pos_neg_pair_t)
         eng = self._get_engine()
         t = pos_neg_pair_t
-        b = t.shape[0]
-        # the batch's rows ride in the last stage's fusion launch (rows this rank owns, zeros elsewhere), then one all-reduce
-        part, rows = eng.forward(self._layer_params(), self.x.detach(), getattr(self, 'att', None), gather=False,
-                                 select_ids=t[:, :3].reshape(-1))
+        if t.dtype != torch.int64 or t.dim() != 2 or t.shape[1] < 3:
+            raise ValueError('triples must be int64 [B, >=3]')
+        # stage by stage with the exchanges in between; the batch's rows ride in the last stage's fusion launch (rows this
+        # rank owns, zeros elsewhere), one all-reduce, then the scorer: engine.PEAEngine.sharded_loss
+        cf_loss, part = eng.sharded_loss(self._layer_params(), self.x, getattr(self, 'att', None), t, self.fc1.weight,
+                                         self.fc1.bias, self.fc2.weight, self.fc2.bias)
         self.cached_repr, self._repr_partial = part, True
-        rows = eng.plan.layout.reduce_rows(rows)
-        local = torch.arange(3 * b, dtype=torch.int64, device=t.device).view(b, 3)
-        cf_loss = _engine.bpr_score(rows, local, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         if self.entity_aware:
             return cf_loss + self.entity_aware_coff * self._entity_reg(t, self.x.detach())
         return cf_loss

@@ -223,6 +223,13 @@ class ShardLayout:
             done.record()
         return rows
 
+    def reduce_rows_(self, rows, group=None):
+        """reduce_rows in place (the buffer a captured graph reads next must keep its address)."""
+        out = self.reduce_rows(rows, group)
+        if out is not rows:
+            rows.copy_(out)
+        return rows
+
     def gather_rows(self, table, ids, group=None):
         """[len(ids), ...] rows table[ids] where every rank only holds the rows it owns: each rank contributes its own
         rows (zeros elsewhere) and the contributions are summed -- one small all-reduce instead of the all-gather of

@@ -272,6 +272,23 @@ int pea_model_stage_fills_exchange(const pea_model *model, int stage);
 int pea_model_num_exchanges(const pea_model *model, int level);
 int pea_model_exchange_desc(const pea_model *model, int level, int k, pea_exchange_desc *out);
 
+/* ------------------------------------------------------------------------------------------------
+ * Launch tape.  No counterpart in the reference (its step is a Python loop over torch ops).  A step of this library is a
+ * fixed sequence of kernel launches whose arguments only change when a buffer moves; for launch-bound sizes (a rank of 8:
+ * ten launches of 10-90 us) building the launch descriptors again every step costs as much host time as the GPU needs to
+ * run them.  pea_tape_begin .. pea_tape_end records every launch the library issues from the calling thread (they also
+ * execute); pea_tape_replay re-issues them on `stream` -- same kernels, same order, arguments captured by value, entering
+ * the stream as ordinary launches (not a hipGraph: a graph replay of the same sequence ran slower).  Validity is the
+ * caller's: replay only while every captured pointer still refers to the same buffer.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pea_tape pea_tape;
+int pea_tape_create(pea_tape **out);
+int pea_tape_destroy(pea_tape *tape);
+int pea_tape_begin(pea_tape *tape);
+int pea_tape_end(pea_tape *tape);
+int pea_tape_length(const pea_tape *tape);
+int pea_tape_replay(const pea_tape *tape, void *stream);
+
 /* messages reduced by one forward (sum over channels/steps of kept edges + self loops), and the
  * algorithmic HBM bytes of SURVEY.md section 8(d) for this model -- the roofline yardstick. */
 int pea_model_stats(const pea_model *model, int64_t *messages, double *algorithmic_bytes);
