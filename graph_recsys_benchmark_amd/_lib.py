@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libpeahip.so')
+LIB_PATH = os.environ.get('PEA_LIB') or os.path.join(_HERE, 'csrc', 'libpeahip.so')   # PEA_LIB: A/B runs of two builds
 
 PEA_OK = 0
 KIND_GAT, KIND_GCN, KIND_SAGE = 0, 1, 2

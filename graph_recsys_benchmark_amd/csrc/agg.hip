@@ -106,20 +106,21 @@ __device__ __forceinline__ void short_rows(const AggGroup &P, const int blk) {
 #pragma unroll
             for (int u = 0; u < U; ++u) a[u] = head_sum<F4T>(dot4(h[u], att_s), lane, pos, F4, pow2);
             float e[U];
-            float mn = st.m;
+            float mx = -INFINITY;                                            // largest logit of the batch, natural units
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float z = leaky(a[u] + a_d, slope);                   // computed for every slot, then selected:
-                e[u] = ok[u] ? z : -INFINITY;                                // no branch, 2^(-inf - m) = 0
-                mn = fmaxf(mn, e[u]);
+                e[u] = ok[u] ? z : -INFINITY;                                // no branch, 2^(-inf) = 0
+                mx = fmaxf(mx, e[u]);
             }
+            const float mn = fmaxf(st.m, mx * kLog2e);                       // running max, log2 domain (finite)
             const float fs = __builtin_amdgcn_exp2f(st.m - mn);
             st.m = mn;
             st.s *= fs;
             st.acc = scale4(st.acc, fs);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float p = __builtin_amdgcn_exp2f(e[u] - mn);  // 0 for the masked slots (mn is finite)
+                const float p = __builtin_amdgcn_exp2f(fmaf(e[u], kLog2e, -mn));  // 0 for the masked slots
                 st.s += p;
                 st.acc = fma4(p, h[u], st.acc);
             }
@@ -223,20 +224,21 @@ __device__ __forceinline__ void long_item(const AggGroup &P, const LongItem it, 
 #pragma unroll
                 for (int u0 = 0; u0 < U; u0 += 4) {
                     float e[4];
-                    float mn = st.m;
+                    float mx = -INFINITY;                                        // largest logit of the batch, natural units
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float z = leaky(a[u0 + u] + a_d, slope);          // computed for every slot, then selected:
-                        e[u] = ok[u0 + u] ? z : -INFINITY;                       // no branch, 2^(-inf - m) = 0
-                        mn = fmaxf(mn, e[u]);
+                        e[u] = ok[u0 + u] ? z : -INFINITY;                       // no branch, 2^(-inf) = 0
+                        mx = fmaxf(mx, e[u]);
                     }
+                    const float mn = fmaxf(st.m, mx * kLog2e);                   // running max, log2 domain (finite)
                     const float fs = __builtin_amdgcn_exp2f(st.m - mn);
                     st.m = mn;
                     st.s *= fs;
                     st.acc = scale4(st.acc, fs);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const float p = __builtin_amdgcn_exp2f(e[u] - mn);  // 0 for the masked slots (mn is finite)
+                        const float p = __builtin_amdgcn_exp2f(fmaf(e[u], kLog2e, -mn));  // 0 for the masked slots
                         st.s += p;
                         st.acc = fma4(p, h[u0 + u], st.acc);
                     }
@@ -397,13 +399,14 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
                 }
                 // one softmax update per 4 edges, as in the thin kernel
                 float e[U];
-                float mn = sm;
+                float mx = -INFINITY;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float z = leaky(a[u] + a_d, slope);
                     e[u] = ok[u] ? z : -INFINITY;
-                    mn = fmaxf(mn, e[u]);
+                    mx = fmaxf(mx, e[u]);
                 }
+                const float mn = fmaxf(sm, mx * kLog2e);    // log2-domain running max, natural logits (agg_common.h: Soft)
                 const float fs = __builtin_amdgcn_exp2f(sm - mn);
                 sm = mn;
                 ss *= fs;
@@ -411,7 +414,7 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
                 for (int v = 0; v < V4; ++v) acc[v] = scale4(acc[v], fs);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const float p = __builtin_amdgcn_exp2f(e[u] - mn);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(e[u], kLog2e, -mn));
                     ss += p;
 #pragma unroll
                     for (int v = 0; v < V4; ++v) acc[v] = fma4(p, h[u][v], acc[v]);
@@ -467,12 +470,10 @@ __device__ __forceinline__ void long_item_fat(const AggGroup &P, const LongItem 
 #pragma unroll
             for (int v = 0; v < V4; ++v) d += dot4(h_self[v], att_s[v]);
             const float e = leaky(head_sum<HL>(d, lane, pos, HL, true) + a_d, slope);
-            // Soft::push: one exp, rescale either the state or the newcomer
-            const float dd = e - sm;
-            const float x = __builtin_amdgcn_exp2f(-fabsf(dd));
-            const bool up = dd > 0.f;
-            const float fs = up ? x : 1.f, p = up ? 1.f : x;
-            sm = up ? e : sm;
+            // Soft::push
+            const float mn = fmaxf(sm, e * kLog2e);
+            const float fs = __builtin_amdgcn_exp2f(sm - mn), p = __builtin_amdgcn_exp2f(fmaf(e, kLog2e, -mn));
+            sm = mn;
             ss = fmaf(ss, fs, p);
 #pragma unroll
             for (int v = 0; v < V4; ++v) {

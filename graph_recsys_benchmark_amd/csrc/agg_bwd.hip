@@ -10,7 +10,7 @@
 //   S pass (source rows, REVERSED relation, gathers g_i):  d a_src_j = sum_i d z_ij
 //                             dT_j = sum_i alpha_ij g_i + att_j d a_src_j + att_i d a_dst_j
 // The softmax statistics (m_i in the log2 domain, S_i) were saved by the forward (AggGroup::stats); logits are
-// recomputed from the rows exactly as in agg.hip (packed att vectors carry log2(e); natural-unit gradients get ln 2).
+// recomputed from the rows exactly as in agg.hip (natural units; the weight is 2^(e log2(e) - m_i), agg_common.h: Soft).
 // Same work decomposition as the forward: short rows per lane subgroup, long rows / hub chunks per wave, hub chunks
 // folded in chunk order by a merge kernel -> bitwise reproducible gradients.
 #include <algorithm>
@@ -19,8 +19,6 @@
 
 namespace pea {
 namespace {
-
-constexpr float kLn2 = 0.69314718055994530942f;
 
 struct RowD {  // row-local state of the D pass
     float4 att_s, g, hself;
@@ -50,7 +48,7 @@ __device__ __forceinline__ RowD load_row_d(const AggGroup &P, int row, int c4, i
 template <int F4T>
 __device__ __forceinline__ float dz_edge_d(const AggGroup &P, const RowD &r, float4 h, int lane, int pos, int F4, bool pow2) {
     const float zl = head_sum<F4T>(dot4(h, r.att_s), lane, pos, F4, pow2) + r.a_d;
-    const float alpha = __builtin_amdgcn_exp2f(leaky(zl, P.neg_slope) - r.m) * r.inv_s;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(leaky(zl, P.neg_slope), kLog2e, -r.m)) * r.inv_s;
     const float dal = head_sum<F4T>(dot4(h, r.g), lane, pos, F4, pow2);
     return alpha * (dal - r.c) * (zl > 0.f ? 1.f : P.neg_slope);
 }
@@ -81,7 +79,7 @@ template <int F4T>
 __device__ __forceinline__ void edge_s(const AggGroup &P, const RowS &r, float4 g, float4 sd, bool ok, int lane, int pos,
                                        int F4, bool pow2, float4 &acc, float &dzs) {
     const float zl = r.a_s + sd.x;
-    const float alpha = __builtin_amdgcn_exp2f(leaky(zl, P.neg_slope) - sd.y) * sd.z;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(leaky(zl, P.neg_slope), kLog2e, -sd.y)) * sd.z;
     const float dal = head_sum<F4T>(dot4(g, r.t), lane, pos, F4, pow2);
     const float dz = alpha * (dal - sd.w) * (zl > 0.f ? 1.f : P.neg_slope);
     if (ok) {
@@ -94,7 +92,7 @@ __device__ __forceinline__ void finish_s(const AggGroup &P, const RowS &r, int r
     const int k = c4 / P.F;
     const float dad = P.da_dst[(size_t)row * P.ld_k + k];
     const float4 at_d = ld4(P.att_dst + c4);
-    const float ws = kLn2 * dzs, wd = kLn2 * dad;  // the packed att vectors carry log2(e)
+    const float ws = dzs, wd = dad;   // natural-unit logits and attention vectors: d z / d T_j = att_j
     float4 o;
     o.x = acc.x + ws * r.att_s.x + wd * at_d.x;
     o.y = acc.y + ws * r.att_s.y + wd * at_d.y;

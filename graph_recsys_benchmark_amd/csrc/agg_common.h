@@ -7,6 +7,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr float kNegBig = -3.0e38f;  // finite "minus infinity" for the running max (no inf-inf NaNs)
+constexpr float kLog2e = 1.44269504088896340736f;
 
 struct AggLaunch {
     int n_groups;
@@ -33,16 +34,17 @@ struct Soft {
     float m, s;
     float4 acc;
     __device__ __forceinline__ void init() { m = kNegBig; s = 0.f; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
-    // logits live in the log2 domain (the packed att vectors carry the log2(e) factor; leaky_relu is positively
-    // homogeneous), so a weight is one v_exp_f32.  One exp per edge: x = 2^-|e - m| rescales either the state
-    // (new max) or the newcomer.
+    // The running max m lives in the log2 domain, the logits e in NATURAL units exactly as the reference forms them
+    // (leaky_relu(x_i . att_i + x_j . att_j), reference GATConv.message): a weight is 2^(e * log2(e) - m), one v_fma_f32 (the
+    // product exact inside it) + one v_exp_f32.  Every weight of a state is relative to the same m, whatever m is, so the
+    // rounding of m itself cancels in acc / s; only the small difference e * log2(e) - m is rounded.  (Round 2 folded
+    // log2(e) into the packed attention vectors instead: one more rounding per vector component, and the exponent inherited
+    // the rounding of the scaled logit -- up to 4x the sequential oracle's error on deep multi-head stacks.)
     __device__ __forceinline__ void push(float e, float4 h) {
-        const float d = e - m;
-        const float x = __builtin_amdgcn_exp2f(-fabsf(d));
-        const bool up = d > 0.f;
-        const float fs = up ? x : 1.f;   // factor on the old state
-        const float p = up ? 1.f : x;    // weight of the new edge
-        m = up ? e : m;
+        const float mn = fmaxf(m, e * kLog2e);
+        const float fs = __builtin_amdgcn_exp2f(m - mn);                    // factor on the old state (1 when the max stays)
+        const float p = __builtin_amdgcn_exp2f(fmaf(e, kLog2e, -mn));       // weight of the new edge
+        m = mn;
         s = fmaf(s, fs, p);
         acc.x = fmaf(acc.x, fs, p * h.x);
         acc.y = fmaf(acc.y, fs, p * h.y);

@@ -774,8 +774,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackLaunch L) {
         for (int o = tid; o < J.HF; o += 256) {
             // log2(e) folded in: the aggregation kernels keep logits in the log2 domain (leaky_relu commutes with a
             // positive scale), so every softmax weight is a single v_exp_f32
-            J.att_dst[o] = J.w1[o] * 1.44269504088896340736f;  // att_i multiplies the TARGET row
-            J.att_src[o] = J.w2[o] * 1.44269504088896340736f;  // att_j multiplies the SOURCE row
+            J.att_dst[o] = J.w1[o];  // att_i multiplies the TARGET row (natural units: the exponent takes log2(e), agg_common.h)
+            J.att_src[o] = J.w2[o];  // att_j multiplies the SOURCE row
         }
     } else if (J.kind == PEA_KIND_GCN) {
         for (int idx = tid; idx < J.in * J.HF; idx += 256) {

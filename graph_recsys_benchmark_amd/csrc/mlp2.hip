@@ -24,7 +24,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float4 ld4m(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-constexpr float kLog2e = 1.44269504088896340736f;
 
 // image of one channel, in floats: [Wt0: HT * ET * 64 * 4][Wt1: HT * 4 * 64 * 4][b0p: 2 * HT * 16]
 __host__ __device__ inline int mlp2_image_floats(int ET, int HT) { return HT * ET * 256 + HT * 1024 + 2 * HT * 16; }
@@ -85,12 +84,12 @@ __global__ __launch_bounds__(256) void mlp2_pack_kernel(const Mlp2Launch L) {
     for (int o = t0; o < OUT; o += ts) {
         L.bias1[C.t1_col + o] = C.b1 ? C.b1[o] : 0.f;
         if (gat) {
-            L.att_src1[C.t1_col + o] = C.att_src1[o] * kLog2e;   // att_j multiplies the SOURCE row
-            L.att_dst1[C.t1_col + o] = C.att_dst1[o] * kLog2e;   // att_i multiplies the TARGET row
+            L.att_src1[C.t1_col + o] = C.att_src1[o];   // att_j multiplies the SOURCE row (natural units, agg_common.h: Soft)
+            L.att_dst1[C.t1_col + o] = C.att_dst1[o];   // att_i multiplies the TARGET row
         }
     }
     if (gat) {
-        // logits of the first layer from x itself: (W x) . att = x . (W^T att); log2(e) folded in like the level-wise pack
+        // logits of the first layer from x itself: (W x) . att = x . (W^T att), natural units
         for (int k = (int)threadIdx.x * kPackSplit + part; k < EMB; k += ts) {
             float s = 0.f, d = 0.f;
             for (int i = 0; i < HID; ++i) {
@@ -98,8 +97,8 @@ __global__ __launch_bounds__(256) void mlp2_pack_kernel(const Mlp2Launch L) {
                 s = fmaf(C.att_src0[i], w, s);
                 d = fmaf(C.att_dst0[i], w, d);
             }
-            C.ws[k] = s * kLog2e;
-            C.wd[k] = d * kLog2e;
+            C.ws[k] = s;
+            C.wd[k] = d;
         }
     }
 }

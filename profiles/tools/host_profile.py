@@ -51,6 +51,17 @@ def main():
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
     print('world %d: enqueue %.1f us/step, enqueue + drain %.1f us/step' % (world, t_enq / steps * 1e6, t_all / steps * 1e6))
+    # the loop above runs into the runtime's queue limit (the host is throttled to the GPU's pace once a few hundred launches
+    # are outstanding): the host's OWN cost per step is what a short burst into an empty queue takes
+    burst, best = 8, 1e9
+    for _ in range(20):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(burst):
+            step()
+        best = min(best, (time.perf_counter() - t0) / burst)
+        torch.cuda.synchronize()
+    print('world %d: host cost %.1f us/step (best of 20 bursts of %d steps into an empty queue)' % (world, best * 1e6, burst))
     if train:     # run the backward on this thread so that cProfile sees PEALossFunction.backward and what it calls
         torch.autograd.set_multithreading_enabled(False)
     pr = cProfile.Profile()
