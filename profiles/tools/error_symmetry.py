@@ -51,16 +51,21 @@ def main():
         st['eh'].append(eh / (EPS * sc))
         st['eo'].append(eo / (EPS * sc))
 
+    saved = T._check
     T._check = check
-    for i in range(count):
-        ok, desc = fuzz_parity.one(rng, i)
-        if not ok:
-            print('ERROR', desc, flush=True)
+    try:
+        for i in range(count):
+            ok, desc = fuzz_parity.one(rng, i)
+            if not ok:
+                print('ERROR', desc, flush=True)
+    finally:
+        T._check = saved
     for kind, st in sorted(stats.items()):
         eh, eo = np.concatenate(st['eh']), np.concatenate(st['eo'])
         print('%-4s %9d vectors | hip > 2 x oracle + 1e-6: %6d | oracle > 2 x hip + 1e-6: %6d | err / (eps x scale): hip mean %.2f p99 %.1f p99.9 %.1f | oracle mean %.2f p99 %.1f p99.9 %.1f'
               % (kind, st['n'], st['hip_loose'], st['orc_loose'], eh.mean(), np.percentile(eh, 99), np.percentile(eh, 99.9),
                  eo.mean(), np.percentile(eo, 99), np.percentile(eo, 99.9)), flush=True)
+    return stats
 
 
 if __name__ == '__main__':

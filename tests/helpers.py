@@ -148,11 +148,23 @@ def f64_forward(kind, sd, edges, steps, heads, channel_aggr, gcn_deg_from='row')
     return fused.numpy(), stack.numpy()
 
 
+EPS32 = 2.0 ** -24
+
+
 def assert_fp32_close(got, want, truth, rtol=1e-5, atol=1e-6, what=''):
     """Passes when `got` is elementwise within rtol/atol of `want`; an element that misses that bound must sit in a
-    ROW (one destination node's output vector, per channel for a [N, P, R] stack) whose error against the float64 `truth` is no larger than 2x the fp32
-    oracle's own error IN THAT SAME ROW plus atol (two valid fp32 summation orders of the same hub row).  The
-    fallback is per row: a bad element cannot hide behind the oracle's worst row elsewhere in the array."""
+    ROW (one destination node's output vector, per channel for a [N, P, R] stack) whose error against the float64 `truth`
+    is no larger than 2x the fp32 oracle's own error IN THAT SAME ROW plus atol plus 16 fp32 ulps of the row's magnitude.
+    The fallback is per row: a bad element cannot hide behind the oracle's worst row elsewhere in the array.
+
+    Why the 16-ulp term, with its measurement (round 3, profiles/tools/error_symmetry.py 300 7 ->
+    profiles/r03/error_symmetry_r03.log: 1.39 M output vectors of 300 random configurations, each side against float64):
+    the two sides are two fp32 evaluation orders of the same expression with the SAME error distribution (error / (eps x
+    row magnitude), GAT: HIP mean 3.66, p99 10.8, p99.9 17.8; oracle mean 3.82, p99 11.5, p99.9 20.8; GCN and SAGE
+    likewise, HIP the smaller in every column), and the ratio of the row maxima of two independent realisations exceeds 2 by
+    chance: `hip > 2 oracle + atol` in 462 / 31 / 26 vectors (GAT / GCN / SAGE) and `oracle > 2 hip + atol` in 797 / 369 /
+    104 -- the oracle trips the bare 2x rule MORE often than the kernel.  16 ulps sits at the p99.9 of either side.  That the
+    kernel is not the looser side is itself a test: tests/test_gpu_fuzz.py::test_hip_is_not_the_looser_side."""
     got, want, truth = np.asarray(got, np.float64), np.asarray(want, np.float64), np.asarray(truth, np.float64)
     bad = np.abs(got - want) > atol + rtol * np.abs(want)
     if not bad.any():
@@ -163,7 +175,7 @@ def assert_fp32_close(got, want, truth, rtol=1e-5, atol=1e-6, what=''):
     e_got = np.abs(g2[bad_rows] - t2[bad_rows]).max(axis=1)
     e_orc = np.abs(w2[bad_rows] - t2[bad_rows]).max(axis=1)
     scale = np.abs(t2[bad_rows]).max(axis=1)
-    ok = e_got <= 2.0 * e_orc + atol
+    ok = e_got <= 2.0 * e_orc + atol + 16.0 * EPS32 * scale
     if not ok.all():
         k = int(np.flatnonzero(~ok)[0])
         raise AssertionError('%s: %d elements in %d rows off; row %d: err vs f64 hip %.3e, fp32 oracle %.3e (row scale %.3e)'
@@ -204,27 +216,40 @@ def oracle_params(model, steps, kind, heads=1):
 from oracle.rows64 import f64_rows_two_step, in_edges_of  # noqa: E402,F401  (shared with bench.py)
 
 
-def assert_fused_close(got_fused, got_stack, want_fused, truth_fused, att, channel_aggr='att', rtol=1e-5, atol=1e-6, what='fused'):
-    """The fused [N, R] table.  First the direct criterion of assert_fp32_close.  The attentive fusion is a softmax over
-    channel logits sum_r X[n,p,r]*att[p,r]: on ill-conditioned cases (deep channels whose activations reach 1e2) it
-    amplifies fp32 differences of the stack that are themselves within tolerance, on both the oracle's and the HIP side.
-    Recorded reason for the fallback: such a case says nothing about the fusion kernel, so the check is decomposed --
-    the stack has already been compared with the oracle by the caller, and here the HIP fusion is compared with a
-    float64 fusion of the HIP path's OWN stack (what the kernel was given), per element at rtol / atol."""
+def assert_fused_close(got_fused, got_stack, want_fused, truth_fused, att, channel_aggr='att', rtol=1e-5, atol=1e-6, what='fused',
+                       truth_stack=None):
+    """The fused [N, R] table.  First the direct criterion of assert_fp32_close against the oracle's table.  The attentive
+    fusion (reference models/base.py:201-203) is a softmax over channel logits s_p = X[n,p,:] . att[p,:]: on ill-conditioned
+    cases (deep channels whose activations reach 1e2) it amplifies fp32 differences of the stack that are themselves within
+    tolerance, on the oracle's side as much as on the HIP side.  For rows that miss the direct criterion the table is
+    therefore checked against the FLOAT64 table (`truth_fused`, the oracle side -- not against a re-fusion of the HIP stack)
+    with a first-order error bound built from what the stack is measured to be off by in that row:
+
+        d fused = sum_p a_p dX_p + sum_p da_p X_p,   da_p = a_p (ds_p - sum_q a_q ds_q),   ds_p = dX_p . att_p
+        |d fused| <= E (1 + 2 Xmax A1)               E = max_p |X_hip - X_f64| in the row (measured), Xmax = max |X_f64|,
+                                                     A1 = max_p ||att_p||_1   ('mean' fusion: |d fused| <= E)
+      + the fusion's own rounding: 8 eps (1 + 2 Xmax A1) Xmax  (P-term weighted sum, softmax weights from fp32 logits)
+
+    so a fused row may be off by what its stack row is off by times the condition number of the channel softmax, and no more.
+    The stack itself has been compared with the oracle by the caller (assert_fp32_close)."""
     try:
         assert_fp32_close(got_fused, want_fused, truth_fused, rtol=rtol, atol=atol, what=what)
         return
     except AssertionError as first:
-        x = np.asarray(got_stack, np.float64)
+        if truth_stack is None:
+            raise
+        x_hip, x64 = np.asarray(got_stack, np.float64), np.asarray(truth_stack, np.float64)
+        err_stack = np.abs(x_hip - x64).max(axis=(1, 2))                       # E per row
+        xmax = np.abs(x64).max(axis=(1, 2))
         if channel_aggr == 'att':
-            logits = (x * np.asarray(att, np.float64).reshape(1, x.shape[1], x.shape[2])).sum(-1)
-            w = np.exp(logits - logits.max(-1, keepdims=True))
-            w /= w.sum(-1, keepdims=True)
-            ref = (x * w[..., None]).sum(1)
+            a1 = np.abs(np.asarray(att, np.float64).reshape(x64.shape[1], x64.shape[2])).sum(-1).max()
+            cond = 1.0 + 2.0 * xmax * a1
         else:
-            ref = x.mean(1)
-        # an fp32 weighted sum of P terms of magnitude s carries a few ulps OF s whatever the size of the result: atol is
-        # taken relative to the magnitude of the row's terms where that exceeds 1
-        terms = np.abs(x).max(axis=(1, 2)).reshape(-1, 1)
-        bad = np.abs(np.asarray(got_fused, np.float64) - ref) > atol * np.maximum(1.0, terms) + rtol * np.abs(ref)
-        assert not bad.any(), '%s (and the fusion of the HIP stack itself is off in %d elements)' % (first, int(bad.sum()))
+            cond = np.ones_like(xmax)
+        bound = err_stack * cond + 8.0 * EPS32 * cond * xmax + atol
+        err = np.abs(np.asarray(got_fused, np.float64) - np.asarray(truth_fused, np.float64)).max(axis=1)
+        bad = err > bound
+        if bad.any():
+            k = int(np.flatnonzero(bad)[0])
+            raise AssertionError('%s (and against float64: row %d off by %.3e, bound %.3e = stack error %.3e x condition %.1f)'
+                                 % (first, k, err[k], bound[k], err_stack[k], cond[k]))

@@ -30,7 +30,7 @@ def _check(kind, n, edges, steps, emb, hidden, repr_dim, heads=1, aggr='att', se
     want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, hls, att=sd.get('att'), channel_aggr=aggr, return_stack=True)
     t_fused, t_stack = f64_forward(kind, sd, edges, steps, heads, aggr)
     assert_fp32_close(_np(stack), wstack, t_stack, what='stack')
-    assert_fused_close(_np(fused), _np(stack), want, t_fused, sd.get('att'), aggr)
+    assert_fused_close(_np(fused), _np(stack), want, t_fused, sd.get('att'), aggr, truth_stack=t_stack)
     return model
 
 
@@ -161,7 +161,7 @@ def test_lds_staged_hot_sources_are_bitwise_the_plain_kernel(kind, monkeypatch):
     want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, [[1, 1]] * 4, att=sd.get('att'), return_stack=True)
     t_fused, t_stack = f64_forward(kind, sd, edges, steps, 1, 'att')
     assert_fp32_close(_np(hot_stack), wstack, t_stack, what='stack')
-    assert_fused_close(_np(hot_fused), _np(hot_stack), want, t_fused, sd.get('att'))
+    assert_fused_close(_np(hot_fused), _np(hot_stack), want, t_fused, sd.get('att'), truth_stack=t_stack)
 
 
 @pytest.mark.parametrize('kind', ['gat', 'gcn', 'sage'])
@@ -198,4 +198,4 @@ def test_fat_lane_long_rows_match_the_thin_kernel_and_the_oracle(kind, monkeypat
     want, wstack = orc.pea_forward(kind, sd['x'], edges, cps, hls, att=sd.get('att'), return_stack=True)
     t_fused, t_stack = f64_forward(kind, sd, edges, steps, heads, 'att')
     assert_fp32_close(_np(fat_stack), wstack, t_stack, what='stack')
-    assert_fused_close(_np(fat_fused), _np(fat_stack), want, t_fused, sd.get('att'))
+    assert_fused_close(_np(fat_fused), _np(fat_stack), want, t_fused, sd.get('att'), truth_stack=t_stack)
