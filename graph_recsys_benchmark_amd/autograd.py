@@ -32,14 +32,15 @@ class _Layout:
         buf = (C.c_int64 * need.value)()
         _lib.check(lib.pea_model_describe(engine._h, buf, need.value, C.byref(need)))
         v = list(buf)
-        self.n_levels, self.ld_x, self.off_x, self.off_dx, self.off_gpack, self.pack_floats = v[:6]
-        i = 6
+        self.n_levels, self.ld_x, self.off_x, self.off_dx, self.off_gpack, self.pack_floats, two_step = v[:7]
+        self.two_step_train = bool(two_step)      # csrc/model.h: pea_model::fused2_train
+        i = 7
         self.levels = []
         for _ in range(self.n_levels):
             names = ('ld_t', 'ld_o', 'off_t', 'off_o', 'off_dt', 'off_do', 'off_side', 'bias_off', 'att_src_off',
-                     'att_dst_off', 'n_units')
-            lv = dict(zip(names, v[i:i + 11]))
-            i += 11
+                     'att_dst_off', 'off_dad', 'off_das', 'ld_k', 'n_units')
+            lv = dict(zip(names, v[i:i + 14]))
+            i += 14
             units = []
             for _ in range(lv['n_units']):
                 un = ('p', 's', 'rel', 'in_w', 'heads', 'F', 'HF', 'last', 'in_col', 't_col', 'o_col', 'b_off', 'ldb',
@@ -202,8 +203,48 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 else:
                     dIn_all[:, u['in_col']:u['in_col'] + u['in_w']] += dagg[:, u['t_col']:u['t_col'] + u['in_w']]
             continue
-        level_call(s, 0)
         units = lv['units']
+        if s == 0 and lay.two_step_train:
+            # Two-step training schedule (csrc/model.h: fused2_train; GAT, one head, single GPU).  dO_0 holds dZ_0, the
+            # gradient of the first transform's pre-activations (masked by the gated product above); A_0 (T_0 region) is the
+            # complete input table of that transform.  Dense half on views: dW_0 = dZ_0^T A_0 and dA_0 = dZ_0 W_0 per channel;
+            # then ONE call runs the softmax passes in x space (bias gradient, D pass, S pass -> per-channel dx parts over A_0).
+            emb = x.shape[1]
+            if 0 not in premasked:      # (every supported width takes the gated product; kept for completeness)
+                dO.mul_(_view(wsf, lv['off_o'], n, lv['ld_o']) > 0)
+            pairs, dense, Ws = [], [], []
+            for u in units:
+                li = first[u['p']] + u['s']
+                c = u['t_col']
+                dZ = dO[:, c:c + u['HF']]
+                pairs.append((dZ, T[:, c:c + emb]))                                  # [HF, emb] = lin.weight's layout
+                dense.append((dZ, layer_params[li][0], dT[:, c:c + emb]))           # dA_0 = dZ_0 W_0
+                Ws.append(layer_params[li][0])
+            dWs = grad_weight(pairs)
+            dense_batch(dense)
+            level_call(0, 0)
+            n_ch = len(units)
+            dx = T[:, :n_ch * emb].unflatten(1, (n_ch, emb)).sum(dim=1)              # the S pass wrote the channels' parts over A_0
+            das = _view(wsf, lv['off_das'], n, lv['ld_k'])
+            dad = _view(wsf, lv['off_dad'], n, lv['ld_k'])
+            d_ws, d_wd = grad_weight([(das, x), (dad, x)])                           # [ld_k, emb]: rows = channels in unit order
+            d_ws, d_wd = d_ws[:n_ch], d_wd[:n_ch]
+            # the logits came from x . ws, x . wd with ws = W_0^T att_j, wd = W_0^T att_i: chain rule, batched over the channels
+            W = torch.stack(Ws)                                                      # [P, HF, emb]
+            att_i = torch.stack([layer_params[first[u['p']] + u['s']][1].reshape(-1) for u in units])   # [P, HF]
+            att_j = torch.stack([layer_params[first[u['p']] + u['s']][2].reshape(-1) for u in units])
+            d_att_j = torch.bmm(W, d_ws.unsqueeze(2)).squeeze(2)
+            d_att_i = torch.bmm(W, d_wd.unsqueeze(2)).squeeze(2)
+            dW_att = att_j.unsqueeze(2) * d_ws.unsqueeze(1) + att_i.unsqueeze(2) * d_wd.unsqueeze(1)
+            for q, u in enumerate(units):
+                li = first[u['p']] + u['s']
+                shape = layer_params[li][1].shape
+                grads[li][0] = dWs[q] + dW_att[q]
+                grads[li][1] = d_att_i[q].view(shape)
+                grads[li][2] = d_att_j[q].view(shape)
+                grads[li][3] = _Slice(lv['bias_off'] + u['t_col'], u['HF'])
+            continue
+        level_call(s, 0)
         if sharded:
             # runs of adjacent channels on one relation: their output-gradient columns (and GAT side records) travel together
             side = _view(wsf, lv['off_side'], n, 4 * max(sum(u['heads'] for u in units), 1)) if kind == 'gat' else None

@@ -349,6 +349,7 @@ struct Mlp2Chan {
     const int *x_slot;
     float *x_buf;                         // exchange buffer + the channel's column inside the group
     int x_ld;
+    int h0_col;                           // training: column of the channel's hidden block in Mlp2Launch::h0
 };
 struct Mlp2Launch {
     int kind, n, emb, hid, out, per_pass;
@@ -369,6 +370,13 @@ struct Mlp2Launch {
     float *r1;
     int64_t ld_r1;
     int64_t ldx, ld_a0, ld_t1;
+    // training (two-step schedule with a backward): the hidden tile H = relu(in W0 + b0) is also stored -- h0 [N, ld_h0], the
+    // channel's block at column t1... of its first-layer unit (h0_col) -- and the input row of a node WITHOUT incoming edges
+    // (x itself) is copied into a0, so that A_0 is the complete input table of the first transform for the backward's
+    // weight-gradient and softmax passes.  Null: inference.
+    float *h0;
+    float *a0_w;                          // writable alias of a0 (training only)
+    int64_t ld_h0;
     Mlp2Chan c[kMaxMlp2Chan];
 };
 size_t mlp2_image_bytes(int kind, int emb, int hid);

@@ -144,7 +144,7 @@ __device__ __forceinline__ void mlp2_load(const Mlp2Launch &L, const int *rows, 
     }
 }
 
-template <int ET, int HT>
+template <int ET, int HT, bool TRAIN>
 __global__ __launch_bounds__((Mlp2Cfg<ET, HT>::kThreads)) void mlp2_kernel(const Mlp2Launch L, const int *__restrict__ rows, int64_t n_rows) {
     constexpr int IMG = HT * ET * 256 + HT * 1024 + 2 * HT * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r32 = lane & 31;
@@ -190,16 +190,27 @@ __global__ __launch_bounds__((Mlp2Cfg<ET, HT>::kThreads)) void mlp2_kernel(const
             f32x16 out;
 #pragma unroll
             for (int v = 0; v < 16; ++v) out[v] = 0.f;
+            // training: keep the hidden tile (register v of tile t = hidden unit 32 t + (v & 3) + 8 (v >> 2) + 4 half of the
+            // lane's row: registers 4g .. 4g+3 are 4 consecutive units, one float4 store) and the input row of an edge-less node
+            float *hrow = (TRAIN && cur.valid) ? L.h0 + cur.row * L.ld_h0 + C.h0_col + 4 * half : nullptr;
+            if (TRAIN && cur.valid && C.deg0[cur.row] != 0) {
+                float *arow = L.a0_w + cur.row * L.ld_a0 + C.a0_col;
+#pragma unroll
+                for (int q = 0; q < ET; ++q) *reinterpret_cast<float4 *>(arow + 4 * (2 * q + half)) = cur.xa[q];
+            }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 w = ld4m(wt1 + ((size_t)(t * 4 + g) * 64 + lane) * 4);
                     const float4 b = ld4m(b0p + t * 16 + 4 * g);
-                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, fmaxf(acc[t][4 * g + 0] + b.x, 0.f), out, 0, 0, 0);
-                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, fmaxf(acc[t][4 * g + 1] + b.y, 0.f), out, 0, 0, 0);
-                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, fmaxf(acc[t][4 * g + 2] + b.z, 0.f), out, 0, 0, 0);
-                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, fmaxf(acc[t][4 * g + 3] + b.w, 0.f), out, 0, 0, 0);
+                    const float4 hv = make_float4(fmaxf(acc[t][4 * g + 0] + b.x, 0.f), fmaxf(acc[t][4 * g + 1] + b.y, 0.f),
+                                                  fmaxf(acc[t][4 * g + 2] + b.z, 0.f), fmaxf(acc[t][4 * g + 3] + b.w, 0.f));
+                    if (TRAIN && hrow) *reinterpret_cast<float4 *>(hrow + 32 * t + 8 * g) = hv;
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, hv.x, out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, hv.y, out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, hv.z, out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, hv.w, out, 0, 0, 0);
                 }
             }
             if (cur.valid) {
@@ -382,9 +393,12 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
     const int passes = (L.n + L.per_pass - 1) / L.per_pass;
     L.per_pass = (L.n + passes - 1) / passes;
     const size_t lds = (size_t)L.per_pass * img;
-    static size_t lds_set = 0;
+    const bool train = !SAGE && L.h0 != nullptr;
+    static size_t lds_set_v[2] = {0, 0};          // per kernel instantiation
+    size_t &lds_set = lds_set_v[train ? 1 : 0];
     const void *fn = SAGE ? reinterpret_cast<const void *>(&mlp2_sage_kernel<ET, HT>)
-                          : reinterpret_cast<const void *>(&mlp2_kernel<ET, HT>);
+                          : train ? reinterpret_cast<const void *>(&mlp2_kernel<ET, HT, true>)
+                                  : reinterpret_cast<const void *>(&mlp2_kernel<ET, HT, false>);
     if (lds > lds_set) {
         PEA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
@@ -415,8 +429,11 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
     ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out * (SAGE ? 2 : 1)));
     if (SAGE) {
         PEA_LAUNCH((mlp2_sage_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
+    } else if (train) {
+        PEA_REQUIRE(L.a0_w != nullptr && L.ld_h0 % 4 == 0, PEA_ERR_ARG, "mlp2: the training variant needs a writable A_0 and an aligned hidden table");
+        PEA_LAUNCH((mlp2_kernel<ET, HT, true>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     } else {
-        PEA_LAUNCH((mlp2_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
+        PEA_LAUNCH((mlp2_kernel<ET, HT, false>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     }
     PEA_HIP(hipGetLastError());
     return PEA_OK;

@@ -70,6 +70,10 @@ int build_schedule(pea_model *m) {
         const bool loops_ok = d.kind == PEA_KIND_SAGE ? !(plan->flags & PEA_PLAN_SELF_LOOPS) : (plan->flags & PEA_PLAN_SELF_LOOPS) != 0;
         m->fused2 = all2 && !m->backward && !m->single_conv && (d.heads == 1 || d.kind != PEA_KIND_GAT) && P <= kMaxMlp2Chan &&
                     mlp2_supported(d.kind, d.emb_dim, d.hidden_size, d.repr_dim) && loops_ok && !(env && atoi(env) == 0);
+        const char *envt = getenv("PEA_FUSED2_TRAIN");
+        m->fused2_train = all2 && m->backward && !m->single_conv && d.kind == PEA_KIND_GAT && d.heads == 1 && P <= kMaxMlp2Chan &&
+                          mlp2_supported(d.kind, d.emb_dim, d.hidden_size, d.repr_dim) && loops_ok && d.emb_dim == d.hidden_size &&
+                          plan->shard_world == 1 && !(envt && atoi(envt) == 0);
         m->ld_a0 = pad_ld(P * d.emb_dim);
     }
     m->levels.assign((size_t)Smax, Level());
@@ -259,7 +263,7 @@ int build_schedule(pea_model *m) {
                 i = j;
             }
         }
-        if (m->fused2 && s == 0) {  // one aggregation group per channel, emb columns wide, one "head"
+        if ((m->fused2 || m->fused2_train) && s == 0) {  // one aggregation group per channel, emb columns wide, one "head"
             size_t p0 = 0;
             for (const Unit &u : L.units) p0 += (size_t)slots_of(m, u.rel) * partial_record_floats(d.emb_dim, d.emb_dim);
             partial = std::max(partial, p0);
@@ -313,7 +317,7 @@ int build_schedule(pea_model *m) {
             }
         }
     }
-    if (m->fused2) {
+    if (m->fused2 || m->fused2_train) {
         m->mlp2_img_off = pack;
         pack = pad_off(pack + (size_t)P * (mlp2_image_bytes(d.kind, d.emb_dim, d.hidden_size) / sizeof(float)));
         m->mlp2_att_off = pack;
@@ -830,6 +834,13 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         ML.t1 = wsf + L1.off_t;
         ML.ld_t1 = L1.ld_t;
         ML.images = pack + m->mlp2_img_off;
+        if (training) {   // fused2_train: keep H (= O_0) and complete A_0 (the backward's input table of the first transform)
+            ML.h0 = wsf + L0.off_o;
+            ML.ld_h0 = L0.ld_o;
+            ML.a0_w = A0;
+            m->last_x = x;
+            m->last_ldx = ldx;
+        }
         ML.bias1 = pack + L1.bias_off;
         ML.att_src1 = kind == PEA_KIND_GAT ? pack + L1.att_src_off : nullptr;
         ML.att_dst1 = kind == PEA_KIND_GAT ? pack + L1.att_dst_off : nullptr;
@@ -915,6 +926,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             C.wd = C.ws + d.emb_dim;
             C.a0_col = (int)ui * d.emb_dim;
             C.t1_col = u1->t_col;
+            C.h0_col = u.t_col;
             C.deg0 = R.deg0;
             PEA_TRY(set_exchange(C, *u1));
             if (kind == PEA_KIND_GAT) {
@@ -954,6 +966,10 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
             a.att_dst = C.wd;
             a.out = A0 + C.a0_col;
             a.ld_out = m->ld_a0;
+            if (training && kind == PEA_KIND_GAT) {   // (max, denominator) per (row, channel) for the x-space backward
+                a.stats = wsf + L0.off_stats + 2 * (int)ui;
+                a.ld_stats = L0.ld_stats;
+            }
             a.self_loop = 1;
             a.neg_slope = d.negative_slope;
             a.partial = partial + part_off;
@@ -982,11 +998,12 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
     PEA_REQUIRE(s_beg >= 0 && s_end <= n_levels, PEA_ERR_ARG, "forward: stage %d of %d", stage, n_levels);
     PEA_REQUIRE(part == PEA_PART_ALL || (sharded && stage >= 0), PEA_ERR_ARG, "forward: parts are stages of a sharded plan");
     const bool splits = m->fused2 && !training;   // only stage 0 of the two-step schedule has a part nobody else reads
+    const bool two_step = (m->fused2 && !training) || (m->fused2_train && training);
     for (int k = s_beg; k < s_end; ++k) {
         if (part == PEA_PART_REST && !(splits && k == 0)) continue;   // everything ran with PEA_PART_SOURCES
         // the two-step schedule packs everything it reads in its own launch (launch_mlp2_pack)
-        if (k == 0 && !(m->fused2 && !training)) PEA_TRY(pack_weights());
-        if (m->fused2 && !training) {
+        if (k == 0 && !two_step) PEA_TRY(pack_weights());
+        if (two_step) {
             if (k == 0) PEA_TRY(run_fused2_stage0());
             else PEA_TRY(run_groups(k, kind == PEA_KIND_GAT ? AGG_GAT : kind == PEA_KIND_GCN ? AGG_GCN : AGG_MEAN));
         } else if (kind == PEA_KIND_SAGE && !m->sage2) {

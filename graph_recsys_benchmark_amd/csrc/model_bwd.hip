@@ -129,6 +129,86 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         return PEA_OK;
     }
 
+    if (m->fused2_train && level == 0) {
+        // Two-step training schedule, first layer, in x space.  Inputs (host mirror: autograd.py): dO_0 = dZ_0, the gradient of
+        // the first transform's pre-activations (relu mask applied by the gated product that wrote it); dA_0 = dZ_0 W_0 in
+        // the dT_0 region; A_0 (the complete input table) in the T_0 region; the forward's softmax statistics.  Here: the bias
+        // gradient, the D pass (destination rows, gathers x rows, c_i = dA_i . A_i), the S pass (source rows over the reversed
+        // relation, gathers dA_i and the side records; per channel  dXp_j = sum_i alpha_ij dA_i + ws d a_src_j + wd d a_dst_j
+        // with ws / wd = W_0^T att_j / att_i) -- written over A_0, which is dead once the D pass has read it.  The host then
+        // sums the channel blocks into dx and reduces d ws / d wd (d a_src / d a_dst against x).
+        PEA_REQUIRE(phase == 0 && !sharded, PEA_ERR_ARG, "backward: the two-step training schedule is single-GPU, phase 0");
+        PEA_REQUIRE(m->last_x != nullptr, PEA_ERR_ARG, "backward: no training forward ran on this model");
+        const float *xin = m->last_x;
+        const int ldx = (int)m->last_ldx;
+        const int E0 = d.emb_dim;
+        float *A0 = T, *dA0 = dT;
+        PEA_MEMSET_ASYNC(wsf + L.off_dad, 0, (size_t)N * (size_t)L.ld_k * sizeof(float), stream);
+        PEA_TRY(launch_colsum(own, L.n_cols, L.n_cols, dO, L.ld_o, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
+        std::vector<AggGroup> gd, gs;
+        size_t part_off = 0;
+        for (size_t ui = 0; ui < L.units.size(); ++ui) {
+            const Unit &u = L.units[ui];
+            const int rr = m->reverse_of[(size_t)u.rel];
+            PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", u.rel);
+            Relation &R = plan->rels[(size_t)u.rel], &Rr = plan->rels[(size_t)rr];
+            const size_t rec = partial_record_floats(E0, E0);
+            PEA_REQUIRE(part_off + (size_t)std::max(R.n_slots, Rr.n_slots) * rec <= m->partial_floats, PEA_ERR_NOMEM,
+                        "backward: hub partial buffer too small for relation %d and its reverse", u.rel);
+            AggGroup a{};
+            a.W = E0;
+            a.F = E0;
+            a.neg_slope = d.negative_slope;
+            a.self_loop = 1;
+            a.partial = partial + part_off;
+            part_off += (size_t)std::max(R.n_slots, Rr.n_slots) * rec;
+            a.att_src = pack + m->mlp2_att_off + (size_t)2 * ui * E0;   // ws = W_0^T att_j (mlp2_pack_kernel)
+            a.att_dst = a.att_src + E0;                                  // wd = W_0^T att_i
+            a.bias = nullptr;
+            a.ld_side = L.ld_side;
+            a.ld_k = L.ld_k;
+            a.ld_g = L.ld_t;
+            AggGroup D = a;
+            fill_lists(D, R);
+            D.feat = xin;
+            D.ld_feat = ldx;
+            D.feat_self = xin;
+            D.ld_self = ldx;
+            D.g_self = dA0 + (size_t)ui * E0;
+            D.o_self = A0 + (size_t)ui * E0;
+            D.stats = wsf + L.off_stats + 2 * (int)ui;
+            D.ld_stats = L.ld_stats;
+            D.side_out = wsf + L.off_side + 4 * (int)ui;
+            D.ksum = wsf + L.off_dad + (int)ui;
+            D.short_rows = R.short_rows + R.n_short0;   // edge-less rows: not visited (no side record, d a_dst = 0)
+            D.n_short = R.n_short - R.n_short0;
+            D.msgs_short = (double)R.edges_short;
+            D.msgs_long = (double)R.edges_long;
+            D.table_rows = (double)R.src_span;
+            gd.push_back(D);
+            AggGroup S = a;
+            fill_lists(S, Rr);
+            S.feat = dA0 + (size_t)ui * E0;
+            S.ld_feat = L.ld_t;
+            S.feat_self = xin;
+            S.ld_self = ldx;
+            S.side = wsf + L.off_side + 4 * (int)ui;
+            S.da_dst = wsf + L.off_dad + (int)ui;
+            S.ksum = wsf + L.off_das + (int)ui;
+            S.out = A0 + (size_t)ui * E0;
+            S.ld_out = L.ld_t;
+            S.deg0_self = R.deg0;
+            S.msgs_short = (double)Rr.edges_short;
+            S.msgs_long = (double)Rr.edges_long;
+            S.table_rows = (double)Rr.src_span;
+            gs.push_back(S);
+        }
+        for (size_t b = 0; b < gd.size(); b += kMaxAggGroups)
+            PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, gd.data() + b, (int)std::min<size_t>(kMaxAggGroups, gd.size() - b), stream));
+        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+            PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        return PEA_OK;
+    }
     PEA_REQUIRE(phase == 0 || phase == 2, PEA_ERR_ARG, "backward: GAT/GCN levels have phases 0 and (sharded) 2");
     PEA_REQUIRE(phase == 0 || sharded, PEA_ERR_ARG, "backward: phase 2 is the second half of a SHARDED level");
     const bool part_a = phase == 0;               // masks, D pass, reductions over what own rows already hold
@@ -275,18 +355,19 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
 }
 
 // Flat description of the schedule for the host mirror (all offsets in floats from the 256-byte aligned workspace base):
-//   [0] n_levels  [1] ld_x  [2] off_x  [3] off_dx  [4] off_gpack  [5] pack_floats  then per level
-//   ld_t ld_o off_t off_o off_dt off_do off_side bias_off att_src_off att_dst_off n_units, then per unit
+//   [0] n_levels  [1] ld_x  [2] off_x  [3] off_dx  [4] off_gpack  [5] pack_floats  [6] two-step training schedule (0 / 1)
+//   then per level  ld_t ld_o off_t off_o off_dt off_do off_side bias_off att_src_off att_dst_off off_dad off_das ld_k n_units,
+//   then per unit
 //   p s rel in_w heads F HF last in_col t_col o_col b_off ldb bias_off
 extern "C" int pea_model_describe(const pea_model *m, int64_t *out, int max_len, int *needed) {
     PEA_REQUIRE(m && needed, PEA_ERR_ARG, "describe: null");
     std::vector<int64_t> v = {(int64_t)m->levels.size(), m->ld_x, (int64_t)m->off_x, (int64_t)m->off_dx,
-                              (int64_t)m->off_gpack, (int64_t)m->pack_floats};
+                              (int64_t)m->off_gpack, (int64_t)m->pack_floats, m->fused2_train ? 1 : 0};
     for (const Level &L : m->levels) {
         const int64_t head[] = {L.ld_t, L.ld_o, (int64_t)L.off_t, (int64_t)L.off_o, (int64_t)L.off_dt, (int64_t)L.off_do,
                                 (int64_t)L.off_side, (int64_t)L.bias_off, (int64_t)L.att_src_off, (int64_t)L.att_dst_off,
-                                (int64_t)L.units.size()};
-        v.insert(v.end(), head, head + 11);
+                                (int64_t)L.off_dad, (int64_t)L.off_das, (int64_t)L.ld_k, (int64_t)L.units.size()};
+        v.insert(v.end(), head, head + 14);
         for (const Unit &u : L.units) {
             const int64_t un[] = {u.p, u.s, u.rel, u.in_w, u.heads, u.F, u.HF, u.last ? 1 : 0, u.in_col, u.t_col, u.o_col,
                                   (int64_t)u.b_off, u.ldb, (int64_t)u.bias_off};
