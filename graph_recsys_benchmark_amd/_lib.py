@@ -54,6 +54,11 @@ class DenseJob(C.Structure):
                 ('n_out', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64), ('gate', C.c_void_p), ('ld_gate', C.c_int64)]
 
 
+class Mlp2BwdChan(C.Structure):
+    _fields_ = [('w0', C.c_void_p), ('w1', C.c_void_p), ('dt1_col', C.c_int), ('h_col', C.c_int), ('dz_col', C.c_int),
+                ('da_col', C.c_int)]
+
+
 class StageOpts(C.Structure):
     _fields_ = [('part', C.c_int), ('sel_ids', C.c_void_p), ('sel_stride', C.c_int64), ('n_sel', C.c_int64),
                 ('sel_out', C.c_void_p), ('err_flag', C.c_void_p)]
@@ -108,6 +113,9 @@ SIGNATURES = {
     'pea_grad_weight_workspace_bytes': (_sz, []),
     'pea_grad_weight': (_int, [_i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_dense_batch': (_int, [_i64, _int, C.POINTER(DenseJob), _vp]),
+    'pea_mlp2_backward_data_workspace_bytes': (_sz, [_int, _int, _int, _int]),
+    'pea_mlp2_backward_data': (_int, [_i64, _int, C.POINTER(Mlp2BwdChan), _int, _int, _int, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
+                                      _i64, _vp, _sz, _vp]),
     'pea_grad_weight_sharded': (_int, [_i64, _int, _int, _int, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_dense_batch_rows': (_int, [_i64, _vp, _int, C.POINTER(DenseJob), _vp]),
     'pea_sample_negatives': (_int, [_i64, _int, _vp, _vp, _i64, _i64, _vp, _i64, C.c_uint64, C.c_uint32, _vp, _i64, _vp, _vp]),

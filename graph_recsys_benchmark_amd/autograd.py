@@ -19,7 +19,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import PARAM_SLOTS, dense_batch, grad_weight
+from .engine import PARAM_SLOTS, dense_batch, grad_weight, mlp2_backward_data
 
 
 class _Layout:
@@ -210,18 +210,21 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             # complete input table of that transform.  Dense half on views: dW_0 = dZ_0^T A_0 and dA_0 = dZ_0 W_0 per channel;
             # then ONE call runs the softmax passes in x space (bias gradient, D pass, S pass -> per-channel dx parts over A_0).
             emb = x.shape[1]
-            if 0 not in premasked:      # (every supported width takes the gated product; kept for completeness)
-                dO.mul_(_view(wsf, lv['off_o'], n, lv['ld_o']) > 0)
-            pairs, dense, Ws = [], [], []
+            # data path of the dense half in ONE launch (csrc/mlp2_bwd.hip): dZ_0 = (dT_1 W_1) masked by H > 0 -> dO_0 region,
+            # dA_0 = dZ_0 W_0 -> dT_0 region, the hidden gradient tile staying in registers between the two products
+            nxt = lay.levels[1]
+            dT1 = _view(wsf, nxt['off_dt'], n, nxt['ld_t'])
+            H = _view(wsf, lv['off_o'], n, lv['ld_o'])
+            u1_of = {u1['p']: u1 for u1 in nxt['units']}
+            chans, pairs, Ws = [], [], []
             for u in units:
                 li = first[u['p']] + u['s']
-                c = u['t_col']
-                dZ = dO[:, c:c + u['HF']]
-                pairs.append((dZ, T[:, c:c + emb]))                                  # [HF, emb] = lin.weight's layout
-                dense.append((dZ, layer_params[li][0], dT[:, c:c + emb]))           # dA_0 = dZ_0 W_0
+                c, u1 = u['t_col'], u1_of[u['p']]
+                chans.append((layer_params[li][0], layer_params[li + 1][0], u1['t_col'], u['o_col'], c, c))
+                pairs.append((dO[:, c:c + u['HF']], T[:, c:c + emb]))                # dW_0 = dZ_0^T A_0: [HF, emb] = lin.weight's layout
                 Ws.append(layer_params[li][0])
+            mlp2_backward_data(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, H, dO, dT)
             dWs = grad_weight(pairs)
-            dense_batch(dense)
             level_call(0, 0)
             n_ch = len(units)
             dx = T[:, :n_ch * emb].unflatten(1, (n_ch, emb)).sum(dim=1)              # the S pass wrote the channels' parts over A_0
@@ -307,7 +310,8 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                     dense.append((dTu, layer_params[li][0].t().contiguous(), dIn) + ((In,) if gated else ()))
             dWs = grad_weight(pairs, shard=shard3)
             to_reduce.extend(dWs)
-            dense_batch(dense, rows=own32)
+            if not (lay.two_step_train and s == 1):      # two-step training: the level-0 branch runs both products fused
+                dense_batch(dense, rows=own32)
             if gated:
                 premasked.add(s - 1)
         for q, u in enumerate(units):

@@ -551,6 +551,37 @@ def dense_batch(triples_, rows=None):
         _lib.check(lib.pea_dense_batch(n, len(triples_), jobs, _lib.current_stream()))
 
 
+_m2b_ws = {}
+
+
+def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da):
+    """Both products of the first layer's backward data path in one launch (csrc/mlp2_bwd.hip): for every channel
+    (w0 [hid, emb], w1 [out, hid], dt1_col, h_col, dz_col, da_col) of `chans`:  dz = (dt1 . w1) where h > 0 else 0;
+    da = dz . w0.  dt1, h, dz, da: float32 [N, ld] views of the training workspace."""
+    lib = _lib.require_device()
+    n = dt1.shape[0]
+    arr = (_lib.Mlp2BwdChan * len(chans))()
+    keep = []
+    for q, (w0, w1, c1, ch, cz, ca) in enumerate(chans):
+        w0, w1 = w0.detach(), w1.detach()
+        if not w0.is_contiguous():
+            w0 = w0.contiguous()
+        if not w1.is_contiguous():
+            w1 = w1.contiguous()
+        keep += [w0, w1]
+        arr[q] = _lib.Mlp2BwdChan(w0.data_ptr(), w1.data_ptr(), int(c1), int(ch), int(cz), int(ca))
+    need = int(lib.pea_mlp2_backward_data_workspace_bytes(len(chans), int(emb), int(hid), int(out)))
+    if need == 0:
+        raise ValueError('mlp2_backward_data: unsupported widths (%d, %d, %d)' % (emb, hid, out))
+    key = (dt1.device, need)
+    ws = _m2b_ws.get(key)
+    if ws is None:
+        ws = _m2b_ws[key] = torch.empty(need, dtype=torch.uint8, device=dt1.device)
+    _lib.check(lib.pea_mlp2_backward_data(n, len(chans), arr, int(emb), int(hid), int(out), _lib.ptr(dt1), dt1.stride(0),
+                                          _lib.ptr(h), h.stride(0), _lib.ptr(dz), dz.stride(0), _lib.ptr(da), da.stride(0),
+                                          _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+
+
 _pending_err = []      # error flags of bpr_score calls that have not been read back yet (one int32 view each)
 
 

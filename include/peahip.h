@@ -193,6 +193,19 @@ size_t pea_grad_weight_workspace_bytes(void);
 int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes,
                     void *stream);
 int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *jobs_host, void *stream);
+/* Two-step training schedule (GAT; csrc/model.h: fused2_train), dense half of the first layer's backward in ONE launch
+ * (csrc/mlp2_bwd.hip) -- loss.backward() (solvers.py:215) through conv_1.lin -> F.relu -> conv_0.lin (models/base.py:138-139):
+ *   dz[n, dz_col:+hid] = (dt1[n, dt1_col:+out] . w1)  where  h[n, h_col:+hid] > 0, else 0     (w1 = layer-2 lin.weight [out, hid])
+ *   da[n, da_col:+emb] =  dz[n, ...] . w0                                                    (w0 = layer-1 lin.weight [hid, emb])
+ * for every channel of the list; emb, hid in {64, 128}, out a multiple of 4 <= 32; all columns / strides multiples of 4. */
+typedef struct pea_mlp2_bwd_chan {
+    const float *w0, *w1;
+    int dt1_col, h_col, dz_col, da_col;
+} pea_mlp2_bwd_chan;
+size_t pea_mlp2_backward_data_workspace_bytes(int n_chan, int emb, int hid, int out);
+int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *chans_host, int emb, int hid, int out,
+                           const float *dt1, int64_t ld_dt1, const float *h, int64_t ld_h, float *dz, int64_t ld_dz,
+                           float *da, int64_t ld_da, void *workspace, size_t workspace_bytes, void *stream);
 /* Sharded training (one rank's share; the host mirror sums the shares with an all-reduce):
  *   pea_grad_weight_sharded  the same reduction over the rows rank `shard_rank` owns (row i -> rank (i / tile) % world)
  *   pea_dense_batch_rows     out = a w on the listed rows only (device int32 [n_rows]; e.g. the rows a rank owns) */
