@@ -116,6 +116,7 @@ SIGNATURES = {
     'pea_mlp2_backward_data_workspace_bytes': (_sz, [_int, _int, _int, _int]),
     'pea_mlp2_backward_data': (_int, [_i64, _int, C.POINTER(Mlp2BwdChan), _int, _int, _int, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
                                       _i64, _vp, _sz, _vp]),
+    'pea_block_sum': (_int, [_i64, _int, _int, _vp, _i64, _vp, _i64, _vp]),
     'pea_grad_weight_sharded': (_int, [_i64, _int, _int, _int, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_dense_batch_rows': (_int, [_i64, _vp, _int, C.POINTER(DenseJob), _vp]),
     'pea_sample_negatives': (_int, [_i64, _int, _vp, _vp, _i64, _i64, _vp, _i64, C.c_uint64, C.c_uint32, _vp, _i64, _vp, _vp]),

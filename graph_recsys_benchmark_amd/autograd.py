@@ -19,7 +19,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import PARAM_SLOTS, dense_batch, grad_weight, mlp2_backward_data
+from .engine import PARAM_SLOTS, block_sum, dense_batch, grad_weight, mlp2_backward_data
 
 
 class _Layout:
@@ -227,7 +227,7 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             dWs = grad_weight(pairs)
             level_call(0, 0)
             n_ch = len(units)
-            dx = T[:, :n_ch * emb].unflatten(1, (n_ch, emb)).sum(dim=1)              # the S pass wrote the channels' parts over A_0
+            dx = block_sum(T, n_ch, emb)                                             # the S pass wrote the channels' parts over A_0
             das = _view(wsf, lv['off_das'], n, lv['ld_k'])
             dad = _view(wsf, lv['off_dad'], n, lv['ld_k'])
             d_ws, d_wd = grad_weight([(das, x), (dad, x)])                           # [ld_k, emb]: rows = channels in unit order
@@ -238,11 +238,12 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             att_j = torch.stack([layer_params[first[u['p']] + u['s']][2].reshape(-1) for u in units])
             d_att_j = torch.bmm(W, d_ws.unsqueeze(2)).squeeze(2)
             d_att_i = torch.bmm(W, d_wd.unsqueeze(2)).squeeze(2)
-            dW_att = att_j.unsqueeze(2) * d_ws.unsqueeze(1) + att_i.unsqueeze(2) * d_wd.unsqueeze(1)
+            dW0 = torch.stack(dWs)
+            dW0.addcmul_(att_j.unsqueeze(2), d_ws.unsqueeze(1)).addcmul_(att_i.unsqueeze(2), d_wd.unsqueeze(1))
             for q, u in enumerate(units):
                 li = first[u['p']] + u['s']
                 shape = layer_params[li][1].shape
-                grads[li][0] = dWs[q] + dW_att[q]
+                grads[li][0] = dW0[q]
                 grads[li][1] = d_att_i[q].view(shape)
                 grads[li][2] = d_att_j[q].view(shape)
                 grads[li][3] = _Slice(lv['bias_off'] + u['t_col'], u['HF'])

@@ -316,3 +316,39 @@ extern "C" int pea_dense_batch_rows(int64_t n_rows, const int32_t *rows, int n_j
     }
     return launch_gemm_batch(jobs.data(), n_jobs, rows, n_rows, (hipStream_t)stream);
 }
+
+
+// out[n, 0:width] = sum_{b < n_blocks} src[n, b * width : (b + 1) * width], blocks added in order b = 0, 1, ... (fixed order:
+// bitwise reproducible).  Two-step training schedule: the first layer's x-space backward leaves one dx part per channel side
+// by side ([N, P * emb]); their sum is dx (reference: autograd sums the gradients of the P uses of self.x, models/base.py:193).
+namespace pea {
+namespace {
+__global__ __launch_bounds__(256) void block_sum_kernel(int64_t n_rows, int n_blocks, int w4, const float *__restrict__ src,
+                                                        int64_t ld, float *__restrict__ dst, int64_t ld_dst) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_rows * w4) return;
+    const int64_t row = idx / w4;
+    const int c = (int)(idx - row * w4) * 4;
+    const float *p = src + row * ld + c;
+    float4 acc = *reinterpret_cast<const float4 *>(p);
+    for (int b = 1; b < n_blocks; ++b) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)b * w4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(dst + row * ld_dst + c) = acc;
+}
+}  // namespace
+}  // namespace pea
+
+extern "C" int pea_block_sum(int64_t n_rows, int n_blocks, int width, const float *src, int64_t ld, float *dst, int64_t ld_dst,
+                             void *stream) {
+    PEA_REQUIRE(n_rows >= 0 && n_blocks > 0 && width > 0 && width % 4 == 0 && src && dst && ld % 4 == 0 && ld_dst % 4 == 0 &&
+                    ld >= (int64_t)n_blocks * width && ld_dst >= width, PEA_ERR_ARG, "block_sum: bad argument");
+    if (n_rows == 0) return PEA_OK;
+    pea::ProfScope ps("block_sum", (hipStream_t)stream, 4.0 * (double)n_rows * width * (n_blocks + 1));
+    const int64_t total = n_rows * (width / 4);
+    PEA_LAUNCH(pea::block_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_rows, n_blocks,
+               width / 4, src, ld, dst, ld_dst);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}

@@ -582,6 +582,16 @@ def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da):
                                           _lib.ptr(ws), ws.numel(), _lib.current_stream()))
 
 
+def block_sum(src, n_blocks, width):
+    """[N, width] = sum of the n_blocks side-by-side column blocks of src [N, >= n_blocks * width] (fixed order)."""
+    lib = _lib.require_device()
+    src = _rows2d(src)
+    out = torch.empty((src.shape[0], width), dtype=torch.float32, device=src.device)
+    _lib.check(lib.pea_block_sum(src.shape[0], int(n_blocks), int(width), _lib.ptr(src), src.stride(0), _lib.ptr(out), out.stride(0),
+                                 _lib.current_stream()))
+    return out
+
+
 _pending_err = []      # error flags of bpr_score calls that have not been read back yet (one int32 view each)
 
 

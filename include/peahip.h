@@ -206,6 +206,10 @@ size_t pea_mlp2_backward_data_workspace_bytes(int n_chan, int emb, int hid, int 
 int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *chans_host, int emb, int hid, int out,
                            const float *dt1, int64_t ld_dt1, const float *h, int64_t ld_h, float *dz, int64_t ld_dz,
                            float *da, int64_t ld_da, void *workspace, size_t workspace_bytes, void *stream);
+/* dst[n, 0:width] = sum over b < n_blocks of src[n, b*width : (b+1)*width] (blocks added in order: reproducible): the sum
+ * of the per-channel dx parts of the two-step training schedule (the P uses of self.x, models/base.py:193).            */
+int pea_block_sum(int64_t n_rows, int n_blocks, int width, const float *src, int64_t ld, float *dst, int64_t ld_dst,
+                  void *stream);
 /* Sharded training (one rank's share; the host mirror sums the shares with an all-reduce):
  *   pea_grad_weight_sharded  the same reduction over the rows rank `shard_rank` owns (row i -> rank (i / tile) % world)
  *   pea_dense_batch_rows     out = a w on the listed rows only (device int32 [n_rows]; e.g. the rows a rank owns) */
