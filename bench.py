@@ -488,6 +488,12 @@ def main():
                 out['roofline_gather'] = kernel_roofline(g[0], g[1], traffic_tab, flops)
         out['kernels_ms_per_step'] = {k: round(v[1] / args.steps, 4) for k, v in
                                       sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    eff_world = max(world, args.emulate_world or 1)
+    if eff_world > 1:
+        out['exchange_model'] = exchange_model(model, eff_world, out.get('kernels_ms_per_step', {}), b, dataset.spec['repr_dim'])
+        if args.emulate_world > 1:
+            out['emulated'] = ('ONE rank (rank 0) of %d on one GPU, collectives skipped: ms_per_step = that rank\'s kernels + host '
+                               'work; value is NOT a job throughput' % args.emulate_world)
     single = world == 1 and args.emulate_world <= 1
     train_steps = args.train_steps if args.train_steps >= 0 else (6 if single else 0)
     if train_steps > 0:          # sharded too: every rank steps its replica with the all-reduced gradients
@@ -515,6 +521,39 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+# xGMI model of the exchanges (NOT measured: no multi-GPU lease was available to this build).  MI355X: 7 links per GPU, 153.6 GB/s
+# per link both directions together = 76.8 GB/s per direction; in an 8-GPU all-gather every rank receives one block from each
+# peer over that peer's own link, so the receive side peaks at (world - 1) x 76.8 GB/s.  RCCL is assumed to reach HALF of that
+# at these message sizes (3.5 MB per rank and peer) and to cost 15 us per collective on top.
+XGMI_GBS_PER_DIRECTION, RCCL_EFFICIENCY, COLLECTIVE_LATENCY_MS = 76.8, 0.5, 0.015
+
+
+def exchange_model(model, world, kernels_ms, batch_rows, repr_dim):
+    """Bytes a rank receives per step and the modelled time of the collectives of the sharded loss step: the all-gathers of
+    the next level's gather sources (issued asynchronously after the rows other ranks read; the rest of the stage runs
+    behind them: its measured kernel time is the overlap window) and the all-reduce of the batch's fused rows."""
+    eng = model._get_engine()
+    recv = 0.0
+    n_coll = 0
+    for row in eng._exchanges:
+        for d, _src, _dst, lay in row:
+            recv += (world - 1) * lay.slots_per_rank * d.width * 4.0
+            n_coll += 1
+    bw = (world - 1) * XGMI_GBS_PER_DIRECTION * RCCL_EFFICIENCY * 1e9
+    gather_ms = recv / bw * 1e3 + COLLECTIVE_LATENCY_MS
+    # the rest-of-stage transform launch is the second (larger) of the two `mlp2_fused` launches of a step
+    window_ms = None
+    reduce_bytes = 3 * batch_rows * repr_dim * 4.0
+    reduce_ms = 2.0 * reduce_bytes * (world - 1) / world / bw * 1e3 + COLLECTIVE_LATENCY_MS
+    return {'source_allgather_bytes_received_per_rank': recv, 'source_allgathers_per_step': n_coll,
+            'source_allgather_ms': gather_ms, 'loss_allreduce_bytes': reduce_bytes, 'loss_allreduce_ms': reduce_ms,
+            'exchange_model_ms': gather_ms + reduce_ms,
+            'overlap': 'the all-gathers run behind the transform of the rows no other rank reads (PEA_PART_REST: about 3/4 of '
+                       'a rank\'s rows on this graph; its share of mlp2_fused is the window, see kernels_ms_per_step)',
+            'assumptions': 'NOT measured. xGMI 76.8 GB/s per link and direction, %d peers, RCCL at %.0f %% of the link rate, '
+                           '%.0f us per collective' % (world - 1, RCCL_EFFICIENCY * 100, COLLECTIVE_LATENCY_MS * 1e3)}
 
 
 def training_leg(dataset, model, batch, args, timed_region, train_steps, world, profile, with_check):
