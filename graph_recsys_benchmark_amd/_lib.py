@@ -41,7 +41,8 @@ class ExchangeDesc(C.Structure):
 
 class GwJob(C.Structure):
     _fields_ = [('a', C.c_void_p), ('lda', C.c_int64), ('ma', C.c_int), ('b', C.c_void_p), ('ldb', C.c_int64),
-                ('nb', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64)]
+                ('nb', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64), ('b_mask', C.c_void_p), ('b_alt', C.c_void_p),
+                ('ldb_alt', C.c_int64)]
 
 
 class XchgJob(C.Structure):

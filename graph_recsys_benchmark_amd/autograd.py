@@ -206,8 +206,8 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
         units = lv['units']
         if s == 0 and lay.two_step_train:
             # Two-step training schedule (csrc/model.h: fused2_train; GAT, one head, single GPU).  dO_0 holds dZ_0, the
-            # gradient of the first transform's pre-activations (masked by the gated product above); A_0 (T_0 region) is the
-            # complete input table of that transform.  Dense half on views: dW_0 = dZ_0^T A_0 and dA_0 = dZ_0 W_0 per channel;
+            # gradient of the first transform's pre-activations (masked by the gated product above); A_0 (T_0 region) holds the
+            # aggregates of the rows with incoming edges (the others' input is x itself).  Dense half on views: dW_0 = dZ_0^T A_0 and dA_0 = dZ_0 W_0 per channel;
             # then ONE call runs the softmax passes in x space (bias gradient, D pass, S pass -> per-channel dx parts over A_0).
             emb = x.shape[1]
             # data path of the dense half in ONE launch (csrc/mlp2_bwd.hip): dZ_0 = (dT_1 W_1) masked by H > 0 -> dO_0 region,
@@ -221,7 +221,8 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 li = first[u['p']] + u['s']
                 c, u1 = u['t_col'], u1_of[u['p']]
                 chans.append((layer_params[li][0], layer_params[li + 1][0], u1['t_col'], u['o_col'], c, c))
-                pairs.append((dO[:, c:c + u['HF']], T[:, c:c + emb]))                # dW_0 = dZ_0^T A_0: [HF, emb] = lin.weight's layout
+                # dW_0 = dZ_0^T In: [HF, emb] = lin.weight's layout; In = A_0 where the node has incoming edges, x where not
+                pairs.append((dO[:, c:c + u['HF']], T[:, c:c + emb], plan.edgeless_mask(u['rel']), x))
                 Ws.append(layer_params[li][0])
             mlp2_backward_data(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, H, dO, dT)
             dWs = grad_weight(pairs)

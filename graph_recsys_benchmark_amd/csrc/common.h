@@ -371,11 +371,9 @@ struct Mlp2Launch {
     int64_t ld_r1;
     int64_t ldx, ld_a0, ld_t1;
     // training (two-step schedule with a backward): the hidden tile H = relu(in W0 + b0) is also stored -- h0 [N, ld_h0], the
-    // channel's block at column t1... of its first-layer unit (h0_col) -- and the input row of a node WITHOUT incoming edges
-    // (x itself) is copied into a0, so that A_0 is the complete input table of the first transform for the backward's
-    // weight-gradient and softmax passes.  Null: inference.
+    // channel's block at column h0_col.  Null: inference.  (The input rows of edge-less nodes are NOT copied into A_0: the
+    // backward's weight-gradient reduction reads x for them, pea_gw_job::b_mask.)
     float *h0;
-    float *a0_w;                          // writable alias of a0 (training only)
     int64_t ld_h0;
     Mlp2Chan c[kMaxMlp2Chan];
 };

@@ -21,6 +21,9 @@ constexpr int kGwParts = 128;     // row parts per job (grid.x)
 constexpr int kGwMaxJobs = 16;    // 64x64 blocks per launch
 struct GwJob {
     const float *a, *b;
+    const unsigned char *b_mask;   // optional [rows]: rows flagged here take their b operand from b_alt (pea_gw_job)
+    const float *b_alt;
+    int64_t ldb_alt;
     int64_t lda, ldb;
     int ma, nb;       // valid columns of this block (<= 16 * MT, <= 16 * NT)
     float *out;       // block origin, row stride ldo
@@ -61,8 +64,10 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
             const int64_t nc = ok ? nr : 0;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[u][mt] = (ok && am[mt]) ? J.a[nc * J.lda + 16 * mt + i] : 0.f;
+            const bool alt = J.b_mask && J.b_mask[nc] != 0;
+            const float *brow = alt ? J.b_alt + nc * J.ldb_alt : J.b + nc * J.ldb;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = (ok && bm[nt]) ? J.b[nc * J.ldb + 16 * nt + i] : 0.f;
+            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = (ok && bm[nt]) ? brow[16 * nt + i] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -126,7 +131,8 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
             const bool ok = n < r1 && nr < M.N;
             const int64_t nc = ok ? nr : 0;
             const float4 va = *reinterpret_cast<const float4 *>(J.a + nc * J.lda + lc);
-            const float4 vb = *reinterpret_cast<const float4 *>(J.b + nc * J.ldb + lc);
+            const bool alt = J.b_mask && J.b_mask[nc] != 0;
+            const float4 vb = *reinterpret_cast<const float4 *>((alt ? J.b_alt + nc * J.ldb_alt : J.b + nc * J.ldb) + lc);
             pa[u] = ok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
             pb[u] = ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -184,7 +190,8 @@ int launch_gw(const GwBatch &Jb, const RowMap &rows, float *partial, double byte
         bool full = MT == 4 && NT == 4;   // every block 64 x 64 with float4-addressable operands: the LDS-staged kernel
         for (int q = 0; q < Jb.n && full; ++q)
             full = Jb.j[q].ma == 64 && Jb.j[q].nb == 64 && Jb.j[q].lda % 4 == 0 && Jb.j[q].ldb % 4 == 0 &&
-                   (reinterpret_cast<uintptr_t>(Jb.j[q].a) | reinterpret_cast<uintptr_t>(Jb.j[q].b)) % 16 == 0;
+                   (reinterpret_cast<uintptr_t>(Jb.j[q].a) | reinterpret_cast<uintptr_t>(Jb.j[q].b)) % 16 == 0 &&
+                   (!Jb.j[q].b_mask || (Jb.j[q].ldb_alt % 4 == 0 && reinterpret_cast<uintptr_t>(Jb.j[q].b_alt) % 16 == 0));
         if (full) {
             PEA_LAUNCH(gw_stage1_lds, dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
         } else {
@@ -233,11 +240,15 @@ extern "C" int pea_grad_weight_sharded(int64_t n_rows, int shard_tile, int shard
         const pea_gw_job &S = jobs_host[q];
         PEA_REQUIRE(S.a && S.b && S.out && S.ma > 0 && S.nb > 0 && S.lda >= S.ma && S.ldb >= S.nb && S.ldo >= S.nb,
                     PEA_ERR_ARG, "grad_weight: job %d malformed", q);
+        PEA_REQUIRE(!S.b_mask || (S.b_alt && S.ldb_alt >= S.nb), PEA_ERR_ARG, "grad_weight: job %d has a row mask but no alternative operand", q);
         for (int i0 = 0; i0 < S.ma; i0 += 64)
             for (int j0 = 0; j0 < S.nb; j0 += 64) {
                 GwJob B;
                 B.a = S.a + i0;
                 B.b = S.b + j0;
+                B.b_mask = S.b_mask;
+                B.b_alt = S.b_mask ? S.b_alt + j0 : nullptr;
+                B.ldb_alt = S.ldb_alt;
                 B.lda = S.lda;
                 B.ldb = S.ldb;
                 B.ma = std::min(64, S.ma - i0);

@@ -191,13 +191,8 @@ __global__ __launch_bounds__((Mlp2Cfg<ET, HT>::kThreads)) void mlp2_kernel(const
 #pragma unroll
             for (int v = 0; v < 16; ++v) out[v] = 0.f;
             // training: keep the hidden tile (register v of tile t = hidden unit 32 t + (v & 3) + 8 (v >> 2) + 4 half of the
-            // lane's row: registers 4g .. 4g+3 are 4 consecutive units, one float4 store) and the input row of an edge-less node
+            // lane's row: registers 4g .. 4g+3 are 4 consecutive units, one float4 store)
             float *hrow = (TRAIN && cur.valid) ? L.h0 + cur.row * L.ld_h0 + C.h0_col + 4 * half : nullptr;
-            if (TRAIN && cur.valid && C.deg0[cur.row] != 0) {
-                float *arow = L.a0_w + cur.row * L.ld_a0 + C.a0_col;
-#pragma unroll
-                for (int q = 0; q < ET; ++q) *reinterpret_cast<float4 *>(arow + 4 * (2 * q + half)) = cur.xa[q];
-            }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
 #pragma unroll
@@ -430,7 +425,7 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
     if (SAGE) {
         PEA_LAUNCH((mlp2_sage_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     } else if (train) {
-        PEA_REQUIRE(L.a0_w != nullptr && L.ld_h0 % 4 == 0, PEA_ERR_ARG, "mlp2: the training variant needs a writable A_0 and an aligned hidden table");
+        PEA_REQUIRE(L.ld_h0 % 4 == 0, PEA_ERR_ARG, "mlp2: the training variant needs an aligned hidden table");
         PEA_LAUNCH((mlp2_kernel<ET, HT, true>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     } else {
         PEA_LAUNCH((mlp2_kernel<ET, HT, false>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);

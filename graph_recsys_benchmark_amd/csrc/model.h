@@ -75,8 +75,8 @@ struct pea_model {
     // layers' transforms to the aggregate (csrc/mlp2.hip): T_0 / O_0 are never materialised.  PEA_FUSED2=0: level-wise.
     bool fused2 = false;
     // The same schedule for TRAINING (round 3; GAT, one head, emb == hidden 64 / 128, single GPU; PEA_FUSED2_TRAIN=0: level-wise):
-    // the first layer aggregates x (softmax statistics kept), the fused transform also stores the hidden tile H = O_0 and
-    // completes A_0 with the x rows of edge-less nodes; the backward then runs the first layer's softmax passes in x space
+    // the first layer aggregates x (softmax statistics kept), the fused transform also stores the hidden tile H = O_0;
+    // the backward then runs the first layer's softmax passes in x space
     // (gather sources: x rows and the rows of dA_0 = dZ_0 W_0) -- T_0 is never built, and the first layer's forward gathers
     // and gradient gathers read the 70 MB table x instead of nine 64-column blocks of a 630 MB one.
     bool fused2_train = false;

@@ -834,10 +834,9 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
         ML.t1 = wsf + L1.off_t;
         ML.ld_t1 = L1.ld_t;
         ML.images = pack + m->mlp2_img_off;
-        if (training) {   // fused2_train: keep H (= O_0) and complete A_0 (the backward's input table of the first transform)
+        if (training) {   // fused2_train: keep H (= O_0) for the backward
             ML.h0 = wsf + L0.off_o;
             ML.ld_h0 = L0.ld_o;
-            ML.a0_w = A0;
             m->last_x = x;
             m->last_ldx = ldx;
         }

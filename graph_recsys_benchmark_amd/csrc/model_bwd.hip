@@ -132,7 +132,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
     if (m->fused2_train && level == 0) {
         // Two-step training schedule, first layer, in x space.  Inputs (host mirror: autograd.py): dO_0 = dZ_0, the gradient of
         // the first transform's pre-activations (relu mask applied by the gated product that wrote it); dA_0 = dZ_0 W_0 in
-        // the dT_0 region; A_0 (the complete input table) in the T_0 region; the forward's softmax statistics.  Here: the bias
+        // the dT_0 region; A_0 (the aggregates of the rows with incoming edges) in the T_0 region; the forward's softmax statistics.  Here: the bias
         // gradient, the D pass (destination rows, gathers x rows, c_i = dA_i . A_i), the S pass (source rows over the reversed
         // relation, gathers dA_i and the side records; per channel  dXp_j = sum_i alpha_ij dA_i + ws d a_src_j + wd d a_dst_j
         // with ws / wd = W_0^T att_j / att_i) -- written over A_0, which is dead once the D pass has read it.  The host then

@@ -142,6 +142,15 @@ class GraphPlan:
                  'slices')
         return dict(zip(names, [int(v) for v in info]))
 
+    def edgeless_mask(self, r):
+        """uint8 [N]: 1 where node n has no kept incoming edge under relation r (GAT / GCN: its conv output is its own
+        transformed row; the two-step schedules feed x[n] instead of an aggregate).  Built once per relation."""
+        cache = self.__dict__.setdefault('_edgeless', {})
+        if r not in cache:
+            rowptr, _ = self.export_csr(r)
+            cache[r] = (rowptr[1:] == rowptr[:-1]).to(torch.uint8).contiguous()
+        return cache[r]
+
     def export_csr(self, r):
         info = self.relation_info(r)
         rowptr = torch.empty(self.num_nodes + 1, dtype=torch.int32, device=self.device)
@@ -490,7 +499,8 @@ _gw_ws = {}
 
 def grad_weight(pairs, shard=None):
     """[a_q^T b_q for (a_q, b_q) in pairs]: a_q [N, ma], b_q [N, nb] float32 views (row strides free) over the same N
-    rows -- the weight gradients of one level in one pair of launches (pea_grad_weight: fixed-order reduction).
+    rows -- the weight gradients of one level in one pair of launches (pea_grad_weight: fixed-order reduction).  A pair may
+    carry (mask uint8 [N], alt [N, nb]): rows flagged in mask take their b operand from alt (include/peahip.h, pea_gw_job).
     shard = (rank, world, tile): this rank's SHARE (the sum over the rows it owns); the caller all-reduces."""
     lib = _lib.require_device()
     if not pairs:
@@ -499,14 +509,18 @@ def grad_weight(pairs, shard=None):
     dev = pairs[0][0].device
     jobs = (_lib.GwJob * len(pairs))()
     outs = []
-    for q, (a, b) in enumerate(pairs):
-        a, b = _rows2d(a), _rows2d(b)
+    for q, item in enumerate(pairs):
+        a, b = _rows2d(item[0]), _rows2d(item[1])
+        mask, alt = (item[2], _rows2d(item[3])) if len(item) > 2 else (None, None)     # rows flagged in mask read alt instead of b
         if a.shape[0] != n or b.shape[0] != n:
             raise ValueError('grad_weight: operands of one call must share the row count')
         out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=dev)
         outs.append(out)
+        if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != n or alt.shape != b.shape):
+            raise ValueError('grad_weight: the row mask must be uint8 [N] and the alternative operand shaped like b')
         jobs[q] = _lib.GwJob(a.data_ptr(), a.stride(0), a.shape[1], b.data_ptr(), b.stride(0), b.shape[1],
-                             out.data_ptr(), out.stride(0))
+                             out.data_ptr(), out.stride(0), None if mask is None else mask.data_ptr(),
+                             None if alt is None else alt.data_ptr(), 0 if alt is None else alt.stride(0))
     ws = _gw_ws.get(dev)
     if ws is None:
         ws = _gw_ws[dev] = torch.empty(int(lib.pea_grad_weight_workspace_bytes()), dtype=torch.uint8, device=dev)

@@ -180,6 +180,11 @@ typedef struct pea_gw_job {
     const float *a; int64_t lda; int ma;
     const float *b; int64_t ldb; int nb;
     float *out; int64_t ldo;
+    /* optional (NULL: none): rows n with b_mask[n] != 0 take their b operand from b_alt[n*ldb_alt + j] instead.  Two-step
+     * training schedule: the input of the first transform is the aggregate A_0[n] where node n has incoming edges under the
+     * channel's first relation and x[n] itself where it has none (b = A_0 block, b_mask = the relation's edge-less flags,
+     * b_alt = x) -- the x rows are never copied into A_0. */
+    const unsigned char *b_mask; const float *b_alt; int64_t ldb_alt;
 } pea_gw_job;
 typedef struct pea_dense_job {
     const float *a; int64_t lda; int k;

@@ -21,6 +21,9 @@ def short(name):
     if m:                        # backward gather passes: MODE 3 = D (destination rows), 4 = S (source rows); bench.py names
         side = 'dst' if m.group(3) == '3' else 'src'
         return 'gat_bwd_%s_g%s' % (side, m.group(2)) if m.group(1) == 'rows' else 'gat_bwd_%s_merge' % side
+    m = re.search(r'mlp2_kernel<\d+, *\d+, *(true|false|0|1)>', name)
+    if m:                        # the training instance also stores the hidden tile: its own line
+        return 'mlp2_kernel_train' if m.group(1) in ('true', '1') else 'mlp2_kernel'
     m = re.search(r'(gemm_mfma|gemm_persist|gemm_skinny)_kernel<(\d+)', name)
     if m:                        # bench.py names: gemm_persist = gemm_mfma_shared / _batch, gemm_skinny = gemm_mfma_narrow
         return '%s_k%s' % (m.group(1), m.group(2))
@@ -35,8 +38,11 @@ def main(root):
         for r in csv.DictReader(open(f[0])):
             k = short(r['Name'])
             if 'pea' in r['Name']:
-                out.setdefault(k, {})['avg_ms'] = float(r['AverageNs']) / 1e6
-                out[k]['calls'] = int(r['Calls'])
+                e = out.setdefault(k, {})
+                calls, tot = int(r['Calls']), float(r['AverageNs']) / 1e6 * int(r['Calls'])
+                e['calls'] = e.get('calls', 0) + calls          # template instances that share a short name are pooled
+                e['_ms'] = e.get('_ms', 0.0) + tot
+                e['avg_ms'] = e['_ms'] / e['calls']
     for sub in ('fetch', 'write', 'l2'):
         f = glob.glob(os.path.join(root, sub, '*', '*_counter_collection.csv'))
         if not f:
@@ -54,6 +60,7 @@ def main(root):
             for c, x in v.items():
                 out.setdefault(k, {})[c + '_per_launch'] = x / n
     for k, v in out.items():
+        v.pop('_ms', None)
         fetch = v.get('FETCH_SIZE_per_launch')
         write = v.get('WRITE_SIZE_per_launch')
         if fetch is not None and write is not None:
@@ -65,7 +72,8 @@ def main(root):
 
 
 BENCH_NAME = {'gemm_persist_k32': 'gemm_mfma_shared', 'gemm_skinny_k4': 'gemm_mfma_narrow',   # names bench.py prints
-              'gemm_persist_k64': 'gemm_mfma_shared', 'gemm_skinny_k8': 'gemm_mfma_narrow', 'mlp2_kernel': 'mlp2_fused', 'mlp2_sage_kernel': 'mlp2_fused'}
+              'gemm_persist_k64': 'gemm_mfma_shared', 'gemm_skinny_k8': 'gemm_mfma_narrow', 'mlp2_kernel': 'mlp2_fused', 'mlp2_sage_kernel': 'mlp2_fused', 'mlp2_kernel_train': 'mlp2_fused',
+              'mlp2_bwd_kernel': 'mlp2_bwd_fused', 'block_sum_kernel': 'block_sum', 'gw_stage1_lds': 'grad_weight', 'gw_stage1': 'grad_weight'}
 
 
 def merge_traffic(res, key, source):

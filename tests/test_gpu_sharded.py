@@ -234,3 +234,55 @@ def test_bench_self_launches_its_ranks():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['parallelism'] == 'rows2'
     assert out['exchange_ms_per_step'] is not None and np.isfinite(out['training_step']['loss'])
+
+
+def _replay_worker(rank, world, port, mode):
+    """engine.PEAEngine.sharded_loss replays its launch sequences (tape / hipGraph / eager): several steps with DIFFERENT
+    batches and weights updated IN PLACE in between must each equal the single-GPU loss bit for bit -- a replay that kept
+    a stale pointer, batch or weight would not."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      PEA_SHARD_REPLAY=mode)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from helpers import build_model, random_hin, random_state_dict
+        torch.cuda.set_device(0)
+        n, blocks, rel = random_hin(29, n_user=2200, n_item=700, n_attr=40, e_u2i=26000, e_attr=1800)
+        u2i, a2i = rel['u2i'], rel['a2i']
+        flip = lambda e: np.ascontiguousarray(e[::-1])
+        edges = [[u2i, flip(u2i)], [flip(u2i), u2i], [a2i, flip(u2i)], [flip(a2i), a2i]]
+        sd = None
+        losses = {}
+        for sharded in (False, True):
+            model = build_model('gat', n, edges, [2] * 4, 64, 64, 16)
+            if sd is None:
+                sd = random_state_dict(model, 13, scale=0.2)
+            model.load_state_dict(sd)
+            model.train()
+            if sharded:
+                model.shard(rank, world, tile=64)
+            rng = np.random.default_rng(8)
+            (u0, u1), (i0, i1) = blocks['u'], blocks['i']
+            out = []
+            with torch.no_grad():
+                for step in range(4):
+                    b = 160 if step < 3 else 96          # the last step changes the batch size (static buffers are rebuilt)
+                    batch = torch.from_numpy(np.stack([rng.integers(u0, u1, b), rng.integers(i0, i1, b),
+                                                       rng.integers(i0, i1, b)], axis=1).astype(np.int64)).cuda()
+                    out.append(model.loss(batch).clone())
+                    for p in model.parameters():         # an optimizer's in-place update
+                        p.mul_(1.0 + 0.01 * (step + 1))
+                if sharded:
+                    eng = model._get_engine()
+                    recs = eng._sl['graphs']
+                    assert (recs is None) == (mode == 'eager')
+                    if mode == 'tape':
+                        assert all(len(t) > 0 for t in recs.values())
+            losses[sharded] = torch.stack(out).cpu()
+        assert torch.equal(losses[True], losses[False]), 'rank %d (%s): %r vs %r' % (rank, mode, losses[True], losses[False])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['tape', 'graph', 'eager'])
+def test_sharded_loss_replay_modes_track_batches_and_weights(mode):
+    mp.spawn(_replay_worker, args=(2, _free_port(), mode), nprocs=2, join=True)

@@ -66,6 +66,23 @@ def _worker(rank, world, port, tile):
         ids = torch.tensor([0, n - 1, 5, 5, tile, tile - 1, 2 * tile + 3, 77], dtype=torch.int64)
         torch.testing.assert_close(shard.gather_rows(local, ids), truth[ids], rtol=0, atol=0)   # `local` is NaN off-rank
 
+        # 3b'. the same exchange when a kernel has already selected the rows (engine: the fusion launch writes the batch's
+        #      rows a rank owns, zeros elsewhere) -- reduce_rows / reduce_rows_ (in place: a replayed launch reads the buffer)
+        mine = shard.owner(ids) == rank
+        picked = torch.where(mine[:, None], truth[ids], torch.zeros(()))
+        torch.testing.assert_close(shard.reduce_rows(picked.clone()), truth[ids], rtol=0, atol=0)
+        buf = picked.clone()
+        assert shard.reduce_rows_(buf) is buf
+        torch.testing.assert_close(buf, truth[ids], rtol=0, atol=0)
+        # 3b''. exchange_sources with the rank's block already in place (packed=True: the producing kernel wrote the rows
+        #       into their slots) and the asynchronous form (gloo: falls back to the blocking exchange, returns no handle)
+        xbuf2 = torch.full((world * lay.slots_per_rank, 8), float('nan'))
+        m = lay.slots_per_rank
+        xbuf2[rank * m:rank * m + lay.own_count, :6] = truth[lay.own_nodes, 2:8]
+        work = shard.exchange_sources(xbuf2, local, lay, col=2, width=6, packed=True, async_op=True)
+        shard.wait_all([work])
+        torch.testing.assert_close(xbuf2[slots, :6], truth[lay.src_nodes, 2:8], rtol=0, atol=0)
+
         # 3c. gradient fill-ins of the sharded backward: every rank has written the rows it owns; the rows of the
         #     relation's source nodes that other ranks own are filled in, one buffer at a time and batched (one exchange
         #     for several buffers / relations; CPU tensors take the per-item path of fill_in_rows_batch)
