@@ -497,8 +497,13 @@ def main():
     single = world == 1 and args.emulate_world <= 1
     train_steps = args.train_steps if args.train_steps >= 0 else (6 if single else 0)
     if train_steps > 0:          # sharded too: every rank steps its replica with the all-reduced gradients
+        snapshot = {k: v.detach().clone() for k, v in model.state_dict().items()}
         out['training_step'] = training_leg(dataset, model, batch, args, timed_region, train_steps, world, profile,
                                             rank == 0 and single and not args.no_cpu_baseline)
+        with torch.no_grad():    # the legs below (eval variant, CPU baseline + full-size parity) see the weights the timed
+            for k, v in model.state_dict().items():   # forward steps above ran on, not the ones Adam has stepped
+                v.copy_(snapshot[k])
+        del snapshot
     if single and not args.no_extras:
         out['eval_variant'] = eval_variant(dataset, model, args, timed_region)
     if rank == 0 and single and not args.no_cpu_baseline:
