@@ -116,7 +116,11 @@ SIGNATURES = {
     'pea_dense_batch': (_int, [_i64, _int, C.POINTER(DenseJob), _vp]),
     'pea_mlp2_backward_data_workspace_bytes': (_sz, [_int, _int, _int, _int]),
     'pea_mlp2_backward_data': (_int, [_i64, _int, C.POINTER(Mlp2BwdChan), _int, _int, _int, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
-                                      _i64, _vp, _sz, _vp]),
+                                      _i64, _vp, _vp, _vp, _sz, _vp]),
+    'pea_rows_nonzero_workspace_bytes': (_sz, [_i64]),
+    'pea_rows_nonzero': (_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pea_grad_weight_rows': (_int, [_i64, _vp, _vp, _i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
+    'pea_model_set_active_rows0': (_int, [_vp, _vp, _vp, _vp]),
     'pea_block_sum': (_int, [_i64, _int, _int, _vp, _i64, _vp, _i64, _vp]),
     'pea_grad_weight_sharded': (_int, [_i64, _int, _int, _int, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_dense_batch_rows': (_int, [_i64, _vp, _int, C.POINTER(DenseJob), _vp]),

@@ -19,7 +19,12 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import PARAM_SLOTS, block_sum, dense_batch, grad_weight, mlp2_backward_data
+from .engine import PARAM_SLOTS, RowSet, block_sum, dense_batch, grad_weight, mlp2_backward_data
+
+
+def _sparse_backward():
+    import os
+    return os.environ.get('PEA_SPARSE_BWD', '1') != '0'
 
 
 class _Layout:
@@ -224,8 +229,12 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 # dW_0 = dZ_0^T In: [HF, emb] = lin.weight's layout; In = A_0 where the node has incoming edges, x where not
                 pairs.append((dO[:, c:c + u['HF']], T[:, c:c + emb], plan.edgeless_mask(u['rel']), x))
                 Ws.append(layer_params[li][0])
-            mlp2_backward_data(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, H, dO, dT)
-            dWs = grad_weight(pairs)
+            live = getattr(engine, '_live_rows', None) if _sparse_backward() else None
+            mlp2_backward_data(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, H, dO, dT, rows=live)
+            dWs = grad_weight(pairs, rows=live)
+            _lib.check(lib.pea_model_set_active_rows0(engine._h, None if live is None else _lib.ptr(live.flags),
+                                                      None if live is None else _lib.ptr(live.ids),
+                                                      None if live is None else _lib.ptr(live.count)))
             level_call(0, 0)
             n_ch = len(units)
             dx = block_sum(T, n_ch, emb)                                             # the S pass wrote the channels' parts over A_0
@@ -310,7 +319,16 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 else:
                     pairs.append((In, dTu))                                     # [in, F]
                     dense.append((dTu, layer_params[li][0].t().contiguous(), dIn) + ((In,) if gated else ()))
-            dWs = grad_weight(pairs, shard=shard3)
+            live = None
+            if lay.two_step_train and s == 1 and _sparse_backward():
+                # Gradient support: the loss read the batch's rows only, so dT_1 is identically zero outside the batch rows and
+                # their layer-2 in-neighbours (about 1/4 of the nodes on the 25m-shaped graph).  The dense half of both layers
+                # and the first layer's gradient gathers walk that row set (built on the device, count never read by the host).
+                live = getattr(engine, '_live_rows', None)
+                if live is None:
+                    live = engine._live_rows = RowSet(n, x.device)
+                live.fill_from(dT, units[-1]['t_col'] + units[-1]['HF'])      # all channels' columns of dT_1
+            dWs = grad_weight(pairs, shard=shard3, rows=live)
             to_reduce.extend(dWs)
             if not (lay.two_step_train and s == 1):      # two-step training: the level-0 branch runs both products fused
                 dense_batch(dense, rows=own32)

@@ -477,8 +477,9 @@ __global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = 64 / C;                    // rows per wave step (1 when T > 1)
     const int rsub = lane / C, cl = lane % C;
-    const int64_t rows_per = (M.n + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(M.n, r0 + rows_per);
+    const int64_t n_all = M.size();
+    const int64_t rows_per = (n_all + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = min(n_all, r0 + rows_per);
     constexpr int NK = TWO ? 2 : 1;
     for (int cb = 0; cb < W; cb += 256 * T) {
         const int wb = min(W - cb, 256 * T);
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) void colsum_stage1(const RowMap M, int W, int 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t qq = q + (int64_t)4 * R * u;
-                int64_t rr = MAPPED ? M.row(qq < r1 ? qq : r0) : qq;
+                int64_t rr = MAPPED ? (qq < r1 ? M.row(qq) : 0) : qq;
                 const bool rv = qq < r1 && (!MAPPED || rr < M.N);
                 if (!rv) rr = 0;
 #pragma unroll
@@ -626,7 +627,7 @@ int launch_colsum2(const RowMap &rows, int W, int F, const float *A, int lda, co
         while (C < w4) C <<= 1;
     }
     const size_t lds_bytes = (size_t)4 * (two ? 2 : 1) * T * 256 * sizeof(float);
-    const bool mapped = rows.world > 1;
+    const bool mapped = rows.world > 1 || rows.list != nullptr;
     if (mapped && two) colsum_dispatch<true, true>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
     else if (mapped) colsum_dispatch<true, false>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);
     else if (two) colsum_dispatch<false, true>(T, lds_bytes, stream, rows, W, F, C, A, lda, S0, S1, lds, part, part_stride);

@@ -231,7 +231,14 @@ struct RowMap {
     int shift = -1;  // log2(tile) when the tile is a power of two (the default 256 is): shifts instead of 64-bit divisions
     int64_t n = 0;   // number of q values
     int64_t N = 0;   // rows of the tables
+    // explicit row list with its length in DEVICE memory (two-step training schedule: the rows whose layer-2 input gradient
+    // is not identically zero, compacted on the device -- the host never learns the count, so nothing synchronises);
+    // n is then the capacity of the list
+    const int *list = nullptr;
+    const int *count = nullptr;
+    __device__ int64_t size() const { return count ? (int64_t)*count : n; }
     __host__ __device__ int64_t row(int64_t q) const {
+        if (list) return list[q];
         if (world == 1) return q;
         if (shift >= 0) return ((((q >> shift) * world) + rank) << shift) + (q & (int64_t)(tile - 1));
         return ((q / tile) * world + rank) * tile + q % tile;
@@ -254,6 +261,15 @@ inline RowMap make_rowmap(int64_t N, int tile, int world, int rank) {
     const int64_t tiles = (N + tile - 1) / tile;                       // all tiles
     const int64_t own_tiles = tiles > rank ? (tiles - rank + world - 1) / world : 0;
     m.n = own_tiles * tile;
+    return m;
+}
+
+inline RowMap make_rowmap_list(int64_t N, const int *list, const int *count_dev, int64_t capacity) {
+    RowMap m;
+    m.N = N;
+    m.n = capacity;
+    m.list = list;
+    m.count = count_dev;
     return m;
 }
 

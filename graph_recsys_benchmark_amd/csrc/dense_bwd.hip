@@ -37,7 +37,7 @@ struct GwBatch {
 // stage 1: partial[job][part][MT*NT tiles][256] = sum over the part's rows of a[n][i] * b[n][j]
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
-    const int64_t n_rows = M.n;   // sharded plans reduce over the rows this rank owns (RowMap), else over all rows
+    const int64_t n_rows = M.size();   // sharded plans reduce over the rows this rank owns (RowMap), else over all rows
     __shared__ float red[3][MT * NT * 256];
     const GwJob &J = Jb.j[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t n = n0 + 16 * u + kq;
-            const int64_t nr = M.row(n < r1 ? n : r0);
+            const int64_t nr = n < r1 ? M.row(n) : 0;
             const bool ok = n < r1 && nr < M.N;
             const int64_t nc = ok ? nr : 0;
 #pragma unroll
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
 // summed four interleaved row subsets and added them; this one adds all rows of the part in order.
 constexpr int kGwLd = 80;
 __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
-    const int64_t n_rows = M.n;
+    const int64_t n_rows = M.size();
     __shared__ float As[2][32][kGwLd], Bs[2][32][kGwLd];
     const GwJob &J = Jb.j[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
@@ -126,23 +126,24 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
     // row flags of the b operand (pea_gw_job::b_mask) are read one chunk AHEAD of the rows they steer: read in the same
     // step, the flag load sat in front of every operand load (a dependent load per row: 0.56 -> 0.84 ms on the nine
     // first-layer blocks of the 25m-shaped graph)
+    // (so are the row ids of a listed row set: list[q] would otherwise sit in front of both operand loads)
     unsigned char fl[2] = {0, 0}, fl_next[2] = {0, 0};
-    auto flags = [&](int64_t base, unsigned char (&f)[2]) {
+    int64_t rid[2] = {-1, -1}, rid_next[2] = {-1, -1};      // -1: past the end of the part
+    auto flags = [&](int64_t base, unsigned char (&f)[2], int64_t (&id)[2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t n = base + lr + 16 * u;
-            const int64_t nr = M.row(n < r1 ? n : r0);
-            const bool ok = n < r1 && nr < M.N;
+            const int64_t nr = n < r1 ? M.row(n) : -1;
+            const bool ok = nr >= 0 && nr < M.N;
+            id[u] = ok ? nr : -1;
             f[u] = (J.b_mask && ok) ? J.b_mask[nr] : (unsigned char)0;
         }
     };
     auto fetch = [&](int64_t base) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t n = base + lr + 16 * u;
-            const int64_t nr = M.row(n < r1 ? n : r0);
-            const bool ok = n < r1 && nr < M.N;
-            const int64_t nc = ok ? nr : 0;
+            const bool ok = rid[u] >= 0;
+            const int64_t nc = ok ? rid[u] : 0;
             const float4 va = *reinterpret_cast<const float4 *>(J.a + nc * J.lda + lc);
             const float4 vb = *reinterpret_cast<const float4 *>((fl[u] ? J.b_alt + nc * J.ldb_alt : J.b + nc * J.ldb) + lc);
             pa[u] = ok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,19 +158,21 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
         }
     };
     if (r0 < r1) {
-        flags(r0, fl);
+        flags(r0, fl, rid);
         fetch(r0);
         stash(0);
-        flags(r0 + 32, fl);
+        flags(r0 + 32, fl, rid);
     }
     int buf = 0;
     for (int64_t base = r0; base < r1; base += 32, buf ^= 1) {
         __syncthreads();
         if (base + 32 < r1) {
-            fetch(base + 32);            // steered by the flags read an iteration ago
-            flags(base + 64, fl_next);
+            fetch(base + 32);            // steered by the row ids / flags read an iteration ago
+            flags(base + 64, fl_next, rid_next);
             fl[0] = fl_next[0];
             fl[1] = fl_next[1];
+            rid[0] = rid_next[0];
+            rid[1] = rid_next[1];
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -238,6 +241,16 @@ extern "C" size_t pea_grad_weight_workspace_bytes(void) {
 extern "C" int pea_grad_weight_sharded(int64_t n_rows, int shard_tile, int shard_world, int shard_rank, int n_jobs,
                                        const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream);
 
+static int grad_weight_impl(const pea::RowMap &rowmap, int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
+extern "C" int pea_grad_weight_rows(int64_t num_rows, const int32_t *rows, const int32_t *count_dev, int64_t capacity, int n_jobs,
+                                    const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream) {
+    PEA_REQUIRE(num_rows > 0 && rows && count_dev && capacity >= 0 && capacity <= num_rows, PEA_ERR_ARG, "grad_weight_rows: bad row list");
+    return grad_weight_impl(pea::make_rowmap_list(num_rows, rows, count_dev, capacity), capacity, n_jobs, jobs_host, workspace,
+                            workspace_bytes, stream);
+}
+
 extern "C" int pea_grad_weight(int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace,
                                size_t workspace_bytes, void *stream) {
     return pea_grad_weight_sharded(n_rows, 1, 1, 0, n_jobs, jobs_host, workspace, workspace_bytes, stream);
@@ -250,7 +263,13 @@ extern "C" int pea_grad_weight_sharded(int64_t n_rows, int shard_tile, int shard
     PEA_REQUIRE(n_rows >= 0 && n_jobs >= 0 && (jobs_host || n_jobs == 0), PEA_ERR_ARG, "grad_weight: bad arguments");
     PEA_REQUIRE(shard_world >= 1 && shard_rank >= 0 && shard_rank < shard_world && shard_tile > 0, PEA_ERR_ARG,
                 "grad_weight: bad shard (rank %d of %d, tile %d)", shard_rank, shard_world, shard_tile);
-    const RowMap rowmap = make_rowmap(n_rows, shard_tile, shard_world, shard_rank);
+    return grad_weight_impl(make_rowmap(n_rows, shard_tile, shard_world, shard_rank), n_rows, n_jobs, jobs_host, workspace,
+                            workspace_bytes, stream);
+}
+
+static int grad_weight_impl(const pea::RowMap &rowmap, int64_t n_rows, int n_jobs, const pea_gw_job *jobs_host, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    PEA_REQUIRE(n_jobs >= 0 && (jobs_host || n_jobs == 0), PEA_ERR_ARG, "grad_weight: bad arguments");
     PEA_REQUIRE(workspace && workspace_bytes >= pea_grad_weight_workspace_bytes(), PEA_ERR_NOMEM, "grad_weight: workspace too small");
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
     // cut every job into <= 64 x 64 blocks, group the blocks by tile shape, one pair of launches per shape and batch

@@ -34,6 +34,8 @@ struct Mlp2BwdLaunch {
     float *dz, *da;
     int64_t ld_dt1, ld_h, ld_dz, ld_da;
     float *images;
+    const int *rows;        // optional: only these rows (ids), *count of them (device memory); null: rows 0 .. n_rows - 1
+    const int *count;
     Mlp2BwdChan c[kMaxBwdChan];
 };
 
@@ -76,7 +78,7 @@ __device__ __forceinline__ void bwd_load(const Mlp2BwdLaunch &L, int64_t n_rows,
     const Mlp2BwdChan &C = L.c[ch];
     const int64_t q0 = tile * 32 + r32;
     in.valid = q0 < n_rows;
-    in.row = in.valid ? q0 : 0;
+    in.row = in.valid ? (L.rows ? (int64_t)L.rows[q0] : q0) : 0;
     const float *dsrc = L.dt1 + in.row * L.ld_dt1 + C.dt1_col;
     const float *hsrc = L.h + in.row * L.ld_h + C.h_col + 4 * half;
 #pragma unroll
@@ -91,7 +93,8 @@ __device__ __forceinline__ void bwd_load(const Mlp2BwdLaunch &L, int64_t n_rows,
 }
 
 template <int HT, int OT, int NQ>
-__global__ __launch_bounds__(512) void mlp2_bwd_kernel(const Mlp2BwdLaunch L, int64_t n_rows) {
+__global__ __launch_bounds__(512) void mlp2_bwd_kernel(const Mlp2BwdLaunch L, int64_t n_rows_max) {
+    const int64_t n_rows = L.count ? (int64_t)*L.count : n_rows_max;   // a listed row set keeps its length on the device
     constexpr int IMG = HT * NQ * 256 + OT * HT * 4 * 256;
     constexpr int WPB = 512 / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r32 = lane & 31;
@@ -236,7 +239,9 @@ extern "C" size_t pea_mlp2_backward_data_workspace_bytes(int n_chan, int emb, in
 
 extern "C" int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *chans_host, int emb, int hid, int out,
                                       const float *dt1, int64_t ld_dt1, const float *h, int64_t ld_h, float *dz, int64_t ld_dz,
-                                      float *da, int64_t ld_da, void *workspace, size_t workspace_bytes, void *stream) {
+                                      float *da, int64_t ld_da, const int32_t *rows, const int32_t *count_dev, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    PEA_REQUIRE((rows == nullptr) == (count_dev == nullptr), PEA_ERR_ARG, "mlp2_backward_data: a row list comes with its device-side count");
     PEA_REQUIRE(n_rows >= 0 && n_chan > 0 && n_chan <= kMaxBwdChan && chans_host, PEA_ERR_ARG, "mlp2_backward_data: %d channels (1..%d)", n_chan, kMaxBwdChan);
     PEA_REQUIRE((emb == 64 || emb == 128) && (hid == 64 || hid == 128) && out >= 4 && out % 4 == 0 && out <= 32, PEA_ERR_ARG,
                 "mlp2_backward_data: unsupported widths (%d, %d, %d)", emb, hid, out);
@@ -258,6 +263,8 @@ extern "C" int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2
     L.ld_dz = ld_dz;
     L.ld_da = ld_da;
     L.images = aligned_ws(workspace);
+    L.rows = rows;
+    L.count = count_dev;
     for (int c = 0; c < n_chan; ++c) {
         const pea_mlp2_bwd_chan &s = chans_host[c];
         PEA_REQUIRE(s.w0 && s.w1 && s.dt1_col % 4 == 0 && s.h_col % 4 == 0 && s.dz_col % 4 == 0 && s.da_col % 4 == 0 &&

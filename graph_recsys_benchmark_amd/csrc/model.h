@@ -80,6 +80,10 @@ struct pea_model {
     // (gather sources: x rows and the rows of dA_0 = dZ_0 W_0) -- T_0 is never built, and the first layer's forward gathers
     // and gradient gathers read the 70 MB table x instead of nine 64-column blocks of a 630 MB one.
     bool fused2_train = false;
+    // two-step training schedule, level 0: rows whose gradient dA_0 is not identically zero (flags [N], compacted ids and
+    // their device-side count: csrc/rows.hip); null: every row
+    const unsigned char *active0 = nullptr;
+    const int *active0_list = nullptr, *active0_count = nullptr;
     const float *last_x = nullptr;        // x of the last training forward (the level-0 backward gathers its rows)
     int64_t last_ldx = 0;
     int ld_a0 = 0;                        // row stride of A_0 (first-layer aggregates of x, P * emb columns), in the T_0 region

@@ -57,6 +57,18 @@ void fill_lists(AggGroup &a, const Relation &R) {
 
 using namespace pea;
 
+// Level 0 of the two-step training schedule: the rows whose input gradient of the first transform is not identically zero
+// (pea_rows_nonzero of dT_1): the softmax passes skip the others (their dA_0 rows are never written), the bias gradient walks
+// the list.  NULL flags: every row.
+extern "C" int pea_model_set_active_rows0(pea_model *m, const unsigned char *flags, const int32_t *list, const int32_t *count_dev) {
+    PEA_REQUIRE(m, PEA_ERR_ARG, "set_active_rows0: null model");
+    PEA_REQUIRE(flags == nullptr || (list != nullptr && count_dev != nullptr), PEA_ERR_ARG, "set_active_rows0: flags come with the list and its count");
+    m->active0 = flags;
+    m->active0_list = flags ? list : nullptr;
+    m->active0_count = flags ? count_dev : nullptr;
+    return PEA_OK;
+}
+
 extern "C" int pea_model_set_active_rows(pea_model *m, const unsigned char *row_active) {
     PEA_REQUIRE(m, PEA_ERR_ARG, "set_active_rows: null model");
     m->active_rows = row_active;
@@ -144,7 +156,8 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         const int E0 = d.emb_dim;
         float *A0 = T, *dA0 = dT;
         PEA_MEMSET_ASYNC(wsf + L.off_dad, 0, (size_t)N * (size_t)L.ld_k * sizeof(float), stream);
-        PEA_TRY(launch_colsum(own, L.n_cols, L.n_cols, dO, L.ld_o, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
+        const RowMap live = m->active0 ? make_rowmap_list(N, m->active0_list, m->active0_count, N) : own;
+        PEA_TRY(launch_colsum(live, L.n_cols, L.n_cols, dO, L.ld_o, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
         std::vector<AggGroup> gd, gs;
         size_t part_off = 0;
         for (size_t ui = 0; ui < L.units.size(); ++ui) {
@@ -168,6 +181,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             a.ld_side = L.ld_side;
             a.ld_k = L.ld_k;
             a.ld_g = L.ld_t;
+            a.row_active = m->active0;   // D: rows with a zero gradient are not gathered for; S: their rows are not gathered
             AggGroup D = a;
             fill_lists(D, R);
             D.feat = xin;

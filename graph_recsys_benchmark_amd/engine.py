@@ -497,7 +497,28 @@ def _rows2d(t):
 _gw_ws = {}
 
 
-def grad_weight(pairs, shard=None):
+class RowSet:
+    """Rows of a table that hold a non-zero, on the device: flags uint8 [N], ids int32 [N] (the first `count` valid, ascending),
+    count int32 [1] -- the host never reads the count (csrc/rows.hip).  Buffers are allocated once and refilled."""
+
+    def __init__(self, n, device):
+        lib = _lib.require_device()
+        self.n = int(n)
+        self.flags = torch.zeros(self.n, dtype=torch.uint8, device=device)
+        self.ids = torch.zeros(self.n, dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+        self._ws = torch.empty(int(lib.pea_rows_nonzero_workspace_bytes(self.n)), dtype=torch.uint8, device=device)
+
+    def fill_from(self, table, width):
+        """flags / ids / count of the rows of table [N, ld] whose first `width` columns hold a non-zero."""
+        table = _rows2d(table)
+        _lib.check(_lib.load().pea_rows_nonzero(self.n, int(width), _lib.ptr(table), table.stride(0), _lib.ptr(self.flags),
+                                                _lib.ptr(self.ids), _lib.ptr(self.count), _lib.ptr(self._ws), self._ws.numel(),
+                                                _lib.current_stream()))
+        return self
+
+
+def grad_weight(pairs, shard=None, rows=None):
     """[a_q^T b_q for (a_q, b_q) in pairs]: a_q [N, ma], b_q [N, nb] float32 views (row strides free) over the same N
     rows -- the weight gradients of one level in one pair of launches (pea_grad_weight: fixed-order reduction).  A pair may
     carry (mask uint8 [N], alt [N, nb]): rows flagged in mask take their b operand from alt (include/peahip.h, pea_gw_job).
@@ -524,7 +545,10 @@ def grad_weight(pairs, shard=None):
     ws = _gw_ws.get(dev)
     if ws is None:
         ws = _gw_ws[dev] = torch.empty(int(lib.pea_grad_weight_workspace_bytes()), dtype=torch.uint8, device=dev)
-    if shard is not None and shard[1] > 1:
+    if rows is not None:        # RowSet: the reduction runs over the listed rows only (the others contribute exact zeros)
+        _lib.check(lib.pea_grad_weight_rows(n, _lib.ptr(rows.ids), _lib.ptr(rows.count), rows.n, len(pairs), jobs, _lib.ptr(ws),
+                                            ws.numel(), _lib.current_stream()))
+    elif shard is not None and shard[1] > 1:
         _lib.check(lib.pea_grad_weight_sharded(n, int(shard[2]), int(shard[1]), int(shard[0]), len(pairs), jobs, _lib.ptr(ws),
                                                ws.numel(), _lib.current_stream()))
     else:
@@ -568,10 +592,10 @@ def dense_batch(triples_, rows=None):
 _m2b_ws = {}
 
 
-def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da):
+def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da, rows=None):
     """Both products of the first layer's backward data path in one launch (csrc/mlp2_bwd.hip): for every channel
     (w0 [hid, emb], w1 [out, hid], dt1_col, h_col, dz_col, da_col) of `chans`:  dz = (dt1 . w1) where h > 0 else 0;
-    da = dz . w0.  dt1, h, dz, da: float32 [N, ld] views of the training workspace."""
+    da = dz . w0.  dt1, h, dz, da: float32 [N, ld] views of the training workspace.  rows (RowSet): the listed rows only."""
     lib = _lib.require_device()
     n = dt1.shape[0]
     arr = (_lib.Mlp2BwdChan * len(chans))()
@@ -593,6 +617,7 @@ def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da):
         ws = _m2b_ws[key] = torch.empty(need, dtype=torch.uint8, device=dt1.device)
     _lib.check(lib.pea_mlp2_backward_data(n, len(chans), arr, int(emb), int(hid), int(out), _lib.ptr(dt1), dt1.stride(0),
                                           _lib.ptr(h), h.stride(0), _lib.ptr(dz), dz.stride(0), _lib.ptr(da), da.stride(0),
+                                          None if rows is None else _lib.ptr(rows.ids), None if rows is None else _lib.ptr(rows.count),
                                           _lib.ptr(ws), ws.numel(), _lib.current_stream()))
 
 

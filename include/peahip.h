@@ -210,7 +210,22 @@ typedef struct pea_mlp2_bwd_chan {
 size_t pea_mlp2_backward_data_workspace_bytes(int n_chan, int emb, int hid, int out);
 int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *chans_host, int emb, int hid, int out,
                            const float *dt1, int64_t ld_dt1, const float *h, int64_t ld_h, float *dz, int64_t ld_dz,
-                           float *da, int64_t ld_da, void *workspace, size_t workspace_bytes, void *stream);
+                           float *da, int64_t ld_da, const int32_t *rows, const int32_t *count_dev, void *workspace,
+                           size_t workspace_bytes, void *stream);
+/* Gradient support of a training step.  The loss reads the batch's rows only (models/base.py:46-48), so the input gradient of
+ * the LAST conv layer is identically zero on every node that is neither a batch row nor an in-neighbour of one.
+ *   pea_rows_nonzero     flags[n] = 1 where src[n, 0:width] holds a non-zero; list = the ids of those rows in ascending order,
+ *                        *count_dev = how many -- all in device memory: the host never reads the count (no synchronisation)
+ *   rows / count_dev     of pea_mlp2_backward_data: compute the listed rows only (NULL, NULL: rows 0 .. n_rows - 1)
+ *   pea_grad_weight_rows pea_grad_weight over the listed rows (capacity = the list's allocation, <= num_rows)
+ *   pea_model_set_active_rows0   level 0 of the two-step training schedule: gradient gathers skip the rows not flagged
+ *                        (their dA_0 rows are never written), the bias gradient walks the list; NULL: every row           */
+size_t pea_rows_nonzero_workspace_bytes(int64_t n_rows);
+int pea_rows_nonzero(int64_t n_rows, int width, const float *src, int64_t ld, unsigned char *flags, int32_t *list,
+                     int32_t *count_dev, void *workspace, size_t workspace_bytes, void *stream);
+int pea_grad_weight_rows(int64_t num_rows, const int32_t *rows, const int32_t *count_dev, int64_t capacity, int n_jobs,
+                         const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream);
+int pea_model_set_active_rows0(pea_model *model, const unsigned char *flags, const int32_t *list, const int32_t *count_dev);
 /* dst[n, 0:width] = sum over b < n_blocks of src[n, b*width : (b+1)*width] (blocks added in order: reproducible): the sum
  * of the per-channel dx parts of the two-step training schedule (the P uses of self.x, models/base.py:193).            */
 int pea_block_sum(int64_t n_rows, int n_blocks, int width, const float *src, int64_t ld, float *dst, int64_t ld_dst,
