@@ -121,6 +121,7 @@ SIGNATURES = {
     'pea_rows_nonzero': (_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pea_grad_weight_rows': (_int, [_i64, _vp, _vp, _i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_model_set_active_rows0': (_int, [_vp, _vp, _vp, _vp]),
+    'pea_rows_zero': (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     'pea_block_sum': (_int, [_i64, _int, _int, _vp, _i64, _vp, _i64, _vp]),
     'pea_grad_weight_sharded': (_int, [_i64, _int, _int, _int, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_dense_batch_rows': (_int, [_i64, _vp, _int, C.POINTER(DenseJob), _vp]),

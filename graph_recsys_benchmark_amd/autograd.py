@@ -230,10 +230,21 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 pairs.append((dO[:, c:c + u['HF']], T[:, c:c + emb], plan.edgeless_mask(u['rel']), x))
                 Ws.append(layer_params[li][0])
             live = getattr(engine, '_live_rows', None) if _sparse_backward() else None
+            if live is not None:
+                # invariant: dA_0 (the dT_0 region) is zero on every row outside this step's list, so the gradient gathers
+                # below need no per-edge test (3/4 of the gathered rows are live: a test costs more than it saves) -- the
+                # whole region is cleared once, afterwards only the rows the previous step wrote
+                sets = engine._live_sets
+                if not sets[3]:
+                    dT.zero_()
+                    sets[3] = True
+                else:
+                    sets[1 - sets[2]].zero_rows_of(dT, len(units) * emb)
+            elif getattr(engine, '_live_sets', None) is not None:
+                engine._live_sets[3] = False         # a dense step writes every row: the invariant starts over
             mlp2_backward_data(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, H, dO, dT, rows=live)
             dWs = grad_weight(pairs, rows=live)
-            _lib.check(lib.pea_model_set_active_rows0(engine._h, None if live is None else _lib.ptr(live.flags),
-                                                      None if live is None else _lib.ptr(live.ids),
+            _lib.check(lib.pea_model_set_active_rows0(engine._h, None, None if live is None else _lib.ptr(live.ids),
                                                       None if live is None else _lib.ptr(live.count)))
             level_call(0, 0)
             n_ch = len(units)
@@ -324,10 +335,13 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                 # Gradient support: the loss read the batch's rows only, so dT_1 is identically zero outside the batch rows and
                 # their layer-2 in-neighbours (about 1/4 of the nodes on the 25m-shaped graph).  The dense half of both layers
                 # and the first layer's gradient gathers walk that row set (built on the device, count never read by the host).
-                live = getattr(engine, '_live_rows', None)
-                if live is None:
-                    live = engine._live_rows = RowSet(n, x.device)
+                sets = getattr(engine, '_live_sets', None)
+                if sets is None:      # two sets: this step's and the previous step's (its rows of dA_0 are zeroed again below)
+                    sets = engine._live_sets = [RowSet(n, x.device), RowSet(n, x.device), 0, False]
+                sets[2] ^= 1
+                live = sets[sets[2]]
                 live.fill_from(dT, units[-1]['t_col'] + units[-1]['HF'])      # all channels' columns of dT_1
+                engine._live_rows = live
             dWs = grad_weight(pairs, shard=shard3, rows=live)
             to_reduce.extend(dWs)
             if not (lay.two_step_train and s == 1):      # two-step training: the level-0 branch runs both products fused

@@ -62,10 +62,11 @@ using namespace pea;
 // the list.  NULL flags: every row.
 extern "C" int pea_model_set_active_rows0(pea_model *m, const unsigned char *flags, const int32_t *list, const int32_t *count_dev) {
     PEA_REQUIRE(m, PEA_ERR_ARG, "set_active_rows0: null model");
-    PEA_REQUIRE(flags == nullptr || (list != nullptr && count_dev != nullptr), PEA_ERR_ARG, "set_active_rows0: flags come with the list and its count");
-    m->active0 = flags;
-    m->active0_list = flags ? list : nullptr;
-    m->active0_count = flags ? count_dev : nullptr;
+    PEA_REQUIRE((list == nullptr) == (count_dev == nullptr) && (flags == nullptr || list != nullptr), PEA_ERR_ARG,
+                "set_active_rows0: a list comes with its count, flags with the list");
+    m->active0 = flags;              // NULL with a list: the gathers run over every row (dA_0 is zero outside the list)
+    m->active0_list = list;
+    m->active0_count = count_dev;
     return PEA_OK;
 }
 
@@ -156,7 +157,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         const int E0 = d.emb_dim;
         float *A0 = T, *dA0 = dT;
         PEA_MEMSET_ASYNC(wsf + L.off_dad, 0, (size_t)N * (size_t)L.ld_k * sizeof(float), stream);
-        const RowMap live = m->active0 ? make_rowmap_list(N, m->active0_list, m->active0_count, N) : own;
+        const RowMap live = m->active0_list ? make_rowmap_list(N, m->active0_list, m->active0_count, N) : own;
         PEA_TRY(launch_colsum(live, L.n_cols, L.n_cols, dO, L.ld_o, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
         std::vector<AggGroup> gd, gs;
         size_t part_off = 0;

@@ -33,6 +33,17 @@ __global__ __launch_bounds__(256) void row_nonzero_kernel(int64_t n_rows, int w4
     if (row < n_rows && sl == 0) flags[row] = (unsigned char)any;
 }
 
+// table[list[q], 0:4*w4] = 0 for q < *count: 16 lanes x float4 per row piece, a fixed grid walking the list
+__global__ __launch_bounds__(256) void rows_zero_kernel(const int *__restrict__ list, const int *__restrict__ count, int w4,
+                                                        float *__restrict__ table, int64_t ld) {
+    const int n = *count;
+    const int sl = threadIdx.x % 16;
+    for (int q = (int)blockIdx.x * 16 + threadIdx.x / 16; q < n; q += (int)gridDim.x * 16) {
+        float *p = table + (int64_t)list[q] * ld;
+        for (int c = sl; c < w4; c += 16) *reinterpret_cast<float4 *>(p + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 size_t select_temp_bytes(int64_t n_rows) {
     size_t bytes = 0;
     (void)rocprim::select(nullptr, bytes, rocprim::counting_iterator<int>(0), (const unsigned char *)nullptr, (int *)nullptr,
@@ -60,5 +71,16 @@ extern "C" int pea_rows_nonzero(int64_t n_rows, int width, const float *src, int
     void *tmp = aligned_ws(workspace);
     PEA_HIP(rocprim::select(tmp, temp, rocprim::counting_iterator<int>(0), (const unsigned char *)flags, list, count_dev,
                             (size_t)n_rows, stream));
+    return PEA_OK;
+}
+
+// table[list[q], 0:width] = 0 for the *count_dev listed rows (the rows a previous training step left non-zero in a table whose
+// other rows are zero by invariant: see autograd.py, two-step training schedule)
+extern "C" int pea_rows_zero(float *table, int64_t ld, int width, const int32_t *list, const int32_t *count_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PEA_REQUIRE(table && list && count_dev && width > 0 && width % 4 == 0 && ld % 4 == 0 && ld >= width, PEA_ERR_ARG, "rows_zero: bad argument");
+    pea::ProfScope ps("rows_zero", stream);
+    PEA_LAUNCH(pea::rows_zero_kernel, dim3(2048), dim3(256), 0, stream, list, count_dev, width / 4, table, ld);
+    PEA_HIP(hipGetLastError());
     return PEA_OK;
 }

@@ -509,6 +509,12 @@ class RowSet:
         self.count = torch.zeros(1, dtype=torch.int32, device=device)
         self._ws = torch.empty(int(lib.pea_rows_nonzero_workspace_bytes(self.n)), dtype=torch.uint8, device=device)
 
+    def zero_rows_of(self, table, width):
+        """table[ids[q], 0:width] = 0 for the listed rows."""
+        table = _rows2d(table)
+        _lib.check(_lib.load().pea_rows_zero(_lib.ptr(table), table.stride(0), int(width), _lib.ptr(self.ids), _lib.ptr(self.count),
+                                             _lib.current_stream()))
+
     def fill_from(self, table, width):
         """flags / ids / count of the rows of table [N, ld] whose first `width` columns hold a non-zero."""
         table = _rows2d(table)

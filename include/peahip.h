@@ -218,14 +218,17 @@ int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *
  *                        *count_dev = how many -- all in device memory: the host never reads the count (no synchronisation)
  *   rows / count_dev     of pea_mlp2_backward_data: compute the listed rows only (NULL, NULL: rows 0 .. n_rows - 1)
  *   pea_grad_weight_rows pea_grad_weight over the listed rows (capacity = the list's allocation, <= num_rows)
- *   pea_model_set_active_rows0   level 0 of the two-step training schedule: gradient gathers skip the rows not flagged
- *                        (their dA_0 rows are never written), the bias gradient walks the list; NULL: every row           */
+ *   pea_model_set_active_rows0   level 0 of the two-step training schedule: the bias gradient walks the list; with flags the
+ *                        gradient gathers also skip the rows not flagged (pays when few rows are live; without flags the
+ *                        caller keeps dA_0 zero outside the list: pea_rows_zero); all NULL: every row                     */
 size_t pea_rows_nonzero_workspace_bytes(int64_t n_rows);
 int pea_rows_nonzero(int64_t n_rows, int width, const float *src, int64_t ld, unsigned char *flags, int32_t *list,
                      int32_t *count_dev, void *workspace, size_t workspace_bytes, void *stream);
 int pea_grad_weight_rows(int64_t num_rows, const int32_t *rows, const int32_t *count_dev, int64_t capacity, int n_jobs,
                          const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream);
 int pea_model_set_active_rows0(pea_model *model, const unsigned char *flags, const int32_t *list, const int32_t *count_dev);
+/* table[list[q], 0:width] = 0 for q < *count_dev: un-does the rows a previous step wrote in a table kept zero elsewhere */
+int pea_rows_zero(float *table, int64_t ld, int width, const int32_t *list, const int32_t *count_dev, void *stream);
 /* dst[n, 0:width] = sum over b < n_blocks of src[n, b*width : (b+1)*width] (blocks added in order: reproducible): the sum
  * of the per-channel dx parts of the two-step training schedule (the P uses of self.x, models/base.py:193).            */
 int pea_block_sum(int64_t n_rows, int n_blocks, int width, const float *src, int64_t ld, float *dst, int64_t ld_dst,
