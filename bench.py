@@ -590,6 +590,10 @@ def training_leg(dataset, model, batch, args, timed_region, train_steps, world, 
                 'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step (torch.optim.Adam, fused=True)'
                         + (' (row-sharded over %d ranks: gradient-row fill-ins, gradient all-reduce, dx all-gather)' % world
                            if world > 1 else '')})
+    live = getattr(model._train_engine, '_live_rows', None) if getattr(model, '_train_engine', None) is not None else None
+    if live is not None:     # rows the loss's gradient reaches beyond the last layer (csrc/rows.hip): the dense backward walks these
+        res['gradient_support_rows'] = int(live.count.item())
+        res['gradient_support_share'] = res['gradient_support_rows'] / float(dataset.num_nodes)
     if profile:
         n_prof = 3
         lib.pea_profile_enable(1)
