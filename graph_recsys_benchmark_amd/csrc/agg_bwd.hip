@@ -53,6 +53,12 @@ __device__ __forceinline__ float dz_edge_d(const AggGroup &P, const RowD &r, flo
     return alpha * (dal - r.c) * (zl > 0.f ? 1.f : P.neg_slope);
 }
 
+// is the gathered row i live?  (bitmap when the host built one, else the byte flags)
+__device__ __forceinline__ bool row_live(const AggGroup &P, int i) {
+    if (P.row_active_bits) return (P.row_active_bits[(unsigned)i >> 5] >> ((unsigned)i & 31u)) & 1u;
+    return P.row_active[i] != 0;
+}
+
 __device__ __forceinline__ void finish_d(const AggGroup &P, const RowD &r, int row, int c4, float dsum) {
     if (c4 % P.F != 0) return;
     const int k = c4 / P.F;
@@ -160,7 +166,7 @@ __device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk)
             for (int u = 0; u < U; ++u) {
                 ok[u] = beg + t + u < end;
                 int i = ok[u] ? P.col[beg + t + u] : 0;
-                if (P.row_active && ok[u] && P.row_active[i] == 0) ok[u] = false, i = 0;
+                if (P.row_active && ok[u] && !row_live(P, i)) ok[u] = false, i = 0;
                 g[u] = ld4(row_at(P.feat + c4, i, P.ld_feat));
                 sd[u] = ld4(row_at(P.side + 4 * k, i, P.ld_side));
             }
@@ -214,22 +220,51 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
     int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
-    if (MODE == AGG_GAT_BWD_S && P.row_active && src >= 0 && P.row_active[src] == 0) src = -1;
+    if (MODE == AGG_GAT_BWD_S && P.row_active && src >= 0 && !row_live(P, src)) src = -1;
+    // Batch-sparse S pass (the last layer: 2.5 % of the gathered rows carry a gradient): the surviving edges of SEVERAL batches
+    // of 64 are queued (edge order kept) and processed together.  Packing each batch on its own (round 2) still paid one
+    // whole 4-edges-per-subgroup iteration for the 1-2 survivors of nearly every batch: 0.32 ms to find and process the
+    // 0.6 M live edges among 24.8 M.
+    __shared__ int live_q[kBlock / kWave][kWave];
+    const int wq = (int)threadIdx.x / kWave;
+    const bool queued = MODE == AGG_GAT_BWD_S && P.row_active != nullptr;
+    int q_n = 0;
     for (int base = it.beg; base < it.end; base += kWave) {
         const int nxt = base + kWave + lane;
         int src_next = nxt < it.end ? P.col[nxt] : -1;
-        if (MODE == AGG_GAT_BWD_S && P.row_active && src_next >= 0 && P.row_active[src_next] == 0) src_next = -1;
+        if (MODE == AGG_GAT_BWD_S && P.row_active && src_next >= 0 && !row_live(P, src_next)) src_next = -1;
         int cnt = min(kWave, it.end - base);
-        if (MODE == AGG_GAT_BWD_S && P.row_active) {
-            // pack the surviving edges of this batch of 64 to the front (order kept): the loop below then costs what
-            // the live edges cost, not what the row's degree costs
+        if (queued) {
             const unsigned long long live = __ballot(src >= 0);
             const int n_live = __popcll(live);
             const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0));
-            const int dst = src >= 0 ? before : n_live + (lane - before);
-            src = __builtin_amdgcn_ds_permute(dst << 2, src);
-            cnt = n_live;
+            const bool last_batch = base + kWave >= it.end;
+            bool flush = false;
+            if (q_n + n_live > kWave) {            // (wave-uniform) the queue cannot take this batch: process it first
+                flush = true;
+            }
+            if (flush) {
+                const int mine = lane < q_n ? live_q[wq][lane] : -1;
+                // process the queue, then start a new one with this batch
+                const int take = q_n;
+                q_n = 0;
+                if (src >= 0) live_q[wq][before] = src;
+                q_n = n_live;
+                src = mine;
+                cnt = take;
+            } else {
+                if (src >= 0) live_q[wq][q_n + before] = src;
+                q_n += n_live;
+                if (!last_batch) {                  // keep collecting
+                    src = src_next;
+                    continue;
+                }
+                src = lane < q_n ? live_q[wq][lane] : -1;
+                cnt = q_n;
+                q_n = 0;
+            }
         }
+        for (int pass = 0; pass < 2; ++pass) {     // (queued, after a flush on the last batch: the new queue is processed too)
         for (int t = 0; t < cnt; t += NSG * U) {
             int jj[U];
             bool ok[U];
@@ -255,6 +290,11 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
                     edge_s<F4T>(P, rs, h[u], sd[u], ok[u], lane, pos, F4, pow2, acc, dsum);
                 }
             }
+        }
+        if (!(queued && q_n > 0 && base + kWave >= it.end)) break;
+        src = lane < q_n ? live_q[wq][lane] : -1;   // the last batch overflowed the queue: what it left behind
+        cnt = q_n;
+        q_n = 0;
         }
         src = src_next;
     }

@@ -89,6 +89,7 @@ struct pea_model {
     int ld_a0 = 0;                        // row stride of A_0 (first-layer aggregates of x, P * emb columns), in the T_0 region
     size_t mlp2_img_off = 0, mlp2_att_off = 0;   // floats from the pack base: weight images, x-space attention vectors
     const unsigned char *active_rows = nullptr;  // pea_model_set_active_rows: rows with a non-zero final-output gradient
+    unsigned *active_bits = nullptr;             // the same as a bitmap, rebuilt by the last level's backward (owned: hipMalloc once)
     std::vector<int> reverse_of;          // relation -> index of the reversed relation in the plan (-1: absent)
     size_t off_dx = 0, off_gpack = 0, gpack_floats = 0, off_colsum = 0;
 };

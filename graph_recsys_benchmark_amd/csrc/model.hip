@@ -1039,6 +1039,7 @@ extern "C" int pea_model_create(const pea_plan *plan, const pea_model_desc *desc
 }
 
 extern "C" int pea_model_destroy(pea_model *model) {
+    if (model) (void)hipFree(model->active_bits);
     delete model;
     return PEA_OK;
 }

@@ -17,6 +17,16 @@ __global__ void fill_kernel(int64_t n, float v, float *p) {
     if (i < n) p[i] = v;
 }
 
+// bits[w] = bit b set where flags[32 w + b] != 0
+__global__ void flags_to_bits_kernel(int64_t N, const unsigned char *__restrict__ flags, unsigned *__restrict__ bits) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = n < N && flags[n] != 0;
+    const unsigned long long b = __ballot(on);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && n < N) bits[n >> 5] = (unsigned)b;
+    if (lane == 32 && n < N) bits[n >> 5] = (unsigned)(b >> 32);
+}
+
 __global__ void invdeg_kernel(int64_t N, const int *__restrict__ rowptr, float *__restrict__ out) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
@@ -245,6 +255,17 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             ri = rj;
         }
     }
+    const unsigned *active_bits = nullptr;
+    if (d.kind == PEA_KIND_GAT && m->active_rows && part_b) {
+        bool any_last = false;
+        for (const GroupPlan &g : L.groups) any_last = any_last || g.last;
+        if (any_last) {   // the S pass tests one flag per gathered row: as a bitmap the flags of all nodes fit a CU's L1
+            if (!m->active_bits) PEA_HIP(hipMalloc((void **)&m->active_bits, (size_t)((N + 63) / 64) * 2 * sizeof(unsigned)));
+            PEA_LAUNCH(flags_to_bits_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, m->active_rows, m->active_bits);
+            PEA_HIP(hipGetLastError());
+            active_bits = m->active_bits;
+        }
+    }
     std::vector<AggGroup> gd, gsrc;
     for (const GroupPlan &g : L.groups) {
         const int rr = m->reverse_of[(size_t)g.rel];
@@ -283,6 +304,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         a.ld_k = L.ld_k;
         a.ld_g = ldg;
         a.row_active = g.last ? m->active_rows : nullptr;  // only the final outputs' gradient is known to be batch-sparse
+        a.row_active_bits = g.last ? active_bits : nullptr;
         // D pass: destination rows of the forward relation, gathers T_j
         AggGroup D = a;
         fill_lists(D, R);
