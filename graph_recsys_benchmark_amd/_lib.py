@@ -42,7 +42,7 @@ class ExchangeDesc(C.Structure):
 class GwJob(C.Structure):
     _fields_ = [('a', C.c_void_p), ('lda', C.c_int64), ('ma', C.c_int), ('b', C.c_void_p), ('ldb', C.c_int64),
                 ('nb', C.c_int), ('out', C.c_void_p), ('ldo', C.c_int64), ('b_mask', C.c_void_p), ('b_alt', C.c_void_p),
-                ('ldb_alt', C.c_int64)]
+                ('ldb_alt', C.c_int64), ('b_alt_scale', C.c_void_p)]
 
 
 class XchgJob(C.Structure):
@@ -116,7 +116,7 @@ SIGNATURES = {
     'pea_dense_batch': (_int, [_i64, _int, C.POINTER(DenseJob), _vp]),
     'pea_mlp2_backward_data_workspace_bytes': (_sz, [_int, _int, _int, _int]),
     'pea_mlp2_backward_data': (_int, [_i64, _int, C.POINTER(Mlp2BwdChan), _int, _int, _int, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
-                                      _i64, _vp, _vp, _vp, _sz, _vp]),
+                                      _i64, _vp, _vp, _int, _vp, _sz, _vp]),
     'pea_rows_nonzero_workspace_bytes': (_sz, [_i64]),
     'pea_rows_nonzero': (_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pea_grad_weight_rows': (_int, [_i64, _vp, _vp, _i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),

@@ -222,12 +222,16 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             H = _view(wsf, lv['off_o'], n, lv['ld_o'])
             u1_of = {u1['p']: u1 for u1 in nxt['units']}
             chans, pairs, Ws = [], [], []
+            gcn = kind == 'gcn'
+            from_col = engine._gcn_from_col if gcn else False
             for u in units:
                 li = first[u['p']] + u['s']
                 c, u1 = u['t_col'], u1_of[u['p']]
                 chans.append((layer_params[li][0], layer_params[li + 1][0], u1['t_col'], u['o_col'], c, c))
-                # dW_0 = dZ_0^T In: [HF, emb] = lin.weight's layout; In = A_0 where the node has incoming edges, x where not
-                pairs.append((dO[:, c:c + u['HF']], T[:, c:c + emb], plan.edgeless_mask(u['rel']), x))
+                # dW_0 = dZ_0^T In ([HF, emb] = GAT lin.weight's layout; GCN's weight is its transpose); In = A_0 where the node
+                # has incoming edges, x where not (GCN: x times the self-loop norm deg^-1)
+                pair = (dO[:, c:c + u['HF']], T[:, c:c + emb], plan.edgeless_mask(u['rel']), x)
+                pairs.append(pair + (plan.gcn_self_norm(u['rel'], from_col),) if gcn else pair)
                 Ws.append(layer_params[li][0])
             live = getattr(engine, '_live_rows', None) if _sparse_backward() else None
             if live is not None:
@@ -242,13 +246,19 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                     sets[1 - sets[2]].zero_rows_of(dT, len(units) * emb)
             elif getattr(engine, '_live_sets', None) is not None:
                 engine._live_sets[3] = False         # a dense step writes every row: the invariant starts over
-            mlp2_backward_data(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, H, dO, dT, rows=live)
+            mlp2_backward_data(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, H, dO, dT, rows=live, weights_in_out=gcn)
             dWs = grad_weight(pairs, rows=live)
             _lib.check(lib.pea_model_set_active_rows0(engine._h, None, None if live is None else _lib.ptr(live.ids),
                                                       None if live is None else _lib.ptr(live.count)))
             level_call(0, 0)
             n_ch = len(units)
             dx = block_sum(T, n_ch, emb)                                             # the S pass wrote the channels' parts over A_0
+            if gcn:                      # no attention vectors: weight [in, out] = the transpose of the reduced block, bias
+                for q, u in enumerate(units):
+                    li = first[u['p']] + u['s']
+                    grads[li][0] = dWs[q].t()
+                    grads[li][1] = _Slice(lv['bias_off'] + u['t_col'], u['HF'])
+                continue
             das = _view(wsf, lv['off_das'], n, lv['ld_k'])
             dad = _view(wsf, lv['off_dad'], n, lv['ld_k'])
             d_ws, d_wd = grad_weight([(das, x), (dad, x)])                           # [ld_k, emb]: rows = channels in unit order

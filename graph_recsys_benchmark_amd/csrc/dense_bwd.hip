@@ -23,6 +23,7 @@ struct GwJob {
     const float *a, *b;
     const unsigned char *b_mask;   // optional [rows]: rows flagged here take their b operand from b_alt (pea_gw_job)
     const float *b_alt;
+    const float *b_alt_scale;      // optional per-row factor on the alternative row
     int64_t ldb_alt;
     int64_t lda, ldb;
     int ma, nb;       // valid columns of this block (<= 16 * MT, <= 16 * NT)
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
             for (int mt = 0; mt < MT; ++mt) av[u][mt] = (ok && am[mt]) ? J.a[nc * J.lda + 16 * mt + i] : 0.f;
             const bool alt = J.b_mask && J.b_mask[nc] != 0;
             const float *brow = alt ? J.b_alt + nc * J.ldb_alt : J.b + nc * J.ldb;
+            const float bs = (alt && J.b_alt_scale) ? J.b_alt_scale[nc] : 1.f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = (ok && bm[nt]) ? brow[16 * nt + i] : 0.f;
+            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = (ok && bm[nt]) ? bs * brow[16 * nt + i] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -145,7 +147,11 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
             const bool ok = rid[u] >= 0;
             const int64_t nc = ok ? rid[u] : 0;
             const float4 va = *reinterpret_cast<const float4 *>(J.a + nc * J.lda + lc);
-            const float4 vb = *reinterpret_cast<const float4 *>((fl[u] ? J.b_alt + nc * J.ldb_alt : J.b + nc * J.ldb) + lc);
+            float4 vb = *reinterpret_cast<const float4 *>((fl[u] ? J.b_alt + nc * J.ldb_alt : J.b + nc * J.ldb) + lc);
+            if (fl[u] && J.b_alt_scale) {
+                const float bs = J.b_alt_scale[nc];
+                vb = make_float4(bs * vb.x, bs * vb.y, bs * vb.z, bs * vb.w);
+            }
             pa[u] = ok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
             pb[u] = ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -286,6 +292,7 @@ static int grad_weight_impl(const pea::RowMap &rowmap, int64_t n_rows, int n_job
                 B.b = S.b + j0;
                 B.b_mask = S.b_mask;
                 B.b_alt = S.b_mask ? S.b_alt + j0 : nullptr;
+                B.b_alt_scale = S.b_mask ? S.b_alt_scale : nullptr;
                 B.ldb_alt = S.ldb_alt;
                 B.lda = S.lda;
                 B.ldb = S.ldb;

@@ -29,6 +29,7 @@ struct Mlp2BwdChan {
 };
 struct Mlp2BwdLaunch {
     int n, emb, hid, out, per_pass, n_groups;
+    int in_out;             // 1: weights are [in, out] (GCNConv.weight), 0: [out, in] (GATConv.lin.weight)
     int blk_start[kMaxBwdChan + 1];
     const float *dt1, *h;
     float *dz, *da;
@@ -53,12 +54,12 @@ __global__ __launch_bounds__(256) void mlp2_bwd_pack_kernel(const Mlp2BwdLaunch 
     for (int idx = t0; idx < HT * NQ * 256; idx += ts) {          // A(i = hidden unit, k = output j) = W1[j, i]
         const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % NQ, t = (idx >> 8) / NQ;
         const int i = 32 * t + (lane & 31), k = 4 * (2 * q + (lane >> 5)) + e;
-        w1t[idx] = k < OUT ? C.w1[(size_t)k * HID + i] : 0.f;
+        w1t[idx] = k < OUT ? (L.in_out ? C.w1[(size_t)i * OUT + k] : C.w1[(size_t)k * HID + i]) : 0.f;
     }
     for (int idx = t0; idx < OT * HT * 1024; idx += ts) {         // A(i = input k, hidden unit u in register order) = W0[u, i]
         const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 3, t = ((idx >> 10) % HT), te = (idx >> 10) / HT;
         const int i = 32 * te + (lane & 31), u = 32 * t + 8 * g + 4 * (lane >> 5) + e;
-        w0t[idx] = C.w0[(size_t)u * EMB + i];
+        w0t[idx] = L.in_out ? C.w0[(size_t)i * HID + u] : C.w0[(size_t)u * EMB + i];
     }
 }
 
@@ -239,8 +240,8 @@ extern "C" size_t pea_mlp2_backward_data_workspace_bytes(int n_chan, int emb, in
 
 extern "C" int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *chans_host, int emb, int hid, int out,
                                       const float *dt1, int64_t ld_dt1, const float *h, int64_t ld_h, float *dz, int64_t ld_dz,
-                                      float *da, int64_t ld_da, const int32_t *rows, const int32_t *count_dev, void *workspace,
-                                      size_t workspace_bytes, void *stream) {
+                                      float *da, int64_t ld_da, const int32_t *rows, const int32_t *count_dev, int weights_in_out,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
     PEA_REQUIRE((rows == nullptr) == (count_dev == nullptr), PEA_ERR_ARG, "mlp2_backward_data: a row list comes with its device-side count");
     PEA_REQUIRE(n_rows >= 0 && n_chan > 0 && n_chan <= kMaxBwdChan && chans_host, PEA_ERR_ARG, "mlp2_backward_data: %d channels (1..%d)", n_chan, kMaxBwdChan);
     PEA_REQUIRE((emb == 64 || emb == 128) && (hid == 64 || hid == 128) && out >= 4 && out % 4 == 0 && out <= 32, PEA_ERR_ARG,
@@ -265,6 +266,7 @@ extern "C" int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2
     L.images = aligned_ws(workspace);
     L.rows = rows;
     L.count = count_dev;
+    L.in_out = weights_in_out ? 1 : 0;
     for (int c = 0; c < n_chan; ++c) {
         const pea_mlp2_bwd_chan &s = chans_host[c];
         PEA_REQUIRE(s.w0 && s.w1 && s.dt1_col % 4 == 0 && s.h_col % 4 == 0 && s.dz_col % 4 == 0 && s.da_col % 4 == 0 &&

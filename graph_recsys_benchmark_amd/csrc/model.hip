@@ -71,7 +71,8 @@ int build_schedule(pea_model *m) {
         m->fused2 = all2 && !m->backward && !m->single_conv && (d.heads == 1 || d.kind != PEA_KIND_GAT) && P <= kMaxMlp2Chan &&
                     mlp2_supported(d.kind, d.emb_dim, d.hidden_size, d.repr_dim) && loops_ok && !(env && atoi(env) == 0);
         const char *envt = getenv("PEA_FUSED2_TRAIN");
-        m->fused2_train = all2 && m->backward && !m->single_conv && d.kind == PEA_KIND_GAT && d.heads == 1 && P <= kMaxMlp2Chan &&
+        m->fused2_train = all2 && m->backward && !m->single_conv && ((d.kind == PEA_KIND_GAT && d.heads == 1) || d.kind == PEA_KIND_GCN) &&
+                          P <= kMaxMlp2Chan &&
                           mlp2_supported(d.kind, d.emb_dim, d.hidden_size, d.repr_dim) && loops_ok && d.emb_dim == d.hidden_size &&
                           plan->shard_world == 1 && !(envt && atoi(envt) == 0);
         m->ld_a0 = pad_ld(P * d.emb_dim);

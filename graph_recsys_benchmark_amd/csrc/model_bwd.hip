@@ -179,6 +179,33 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             const size_t rec = partial_record_floats(E0, E0);
             PEA_REQUIRE(part_off + (size_t)std::max(R.n_slots, Rr.n_slots) * rec <= m->partial_floats, PEA_ERR_NOMEM,
                         "backward: hub partial buffer too small for relation %d and its reverse", u.rel);
+            if (d.kind == PEA_KIND_GCN) {
+                // GCN: the aggregation is linear, its backward is the same weighted sum over the REVERSED relation, in x space:
+                // dXp_j = sum_i dinv_j dinv_i dA_i + dinv_j^2 dA_j (norm of the forward relation: GCNConv)
+                const bool fc = d.gcn_deg_from_col != 0;
+                PEA_TRY(ensure_dinv(plan, u.rel, fc, stream));
+                AggGroup a{};
+                fill_lists(a, Rr);
+                a.W = E0;
+                a.F = E0;
+                a.self_loop = 1;
+                a.partial = partial + part_off;
+                part_off += (size_t)std::max(R.n_slots, Rr.n_slots) * rec;
+                a.feat = dA0 + (size_t)ui * E0;
+                a.ld_feat = L.ld_t;
+                a.feat_self = a.feat;
+                a.ld_self = L.ld_t;
+                a.dinv = fc ? R.dinv_col : R.dinv_row;
+                a.dinv_self = a.dinv;
+                a.out = A0 + (size_t)ui * E0;
+                a.ld_out = L.ld_t;
+                a.msgs_short = (double)Rr.edges_short;
+                a.msgs_long = (double)Rr.edges_long;
+                a.idx_share = 1.0;
+                a.table_rows = (double)Rr.src_span;
+                gs.push_back(a);
+                continue;
+            }
             AggGroup a{};
             a.W = E0;
             a.F = E0;
@@ -230,8 +257,11 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         }
         for (size_t b = 0; b < gd.size(); b += kMaxAggGroups)
             PEA_TRY(launch_gat_backward(AGG_GAT_BWD_D, gd.data() + b, (int)std::min<size_t>(kMaxAggGroups, gd.size() - b), stream));
-        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
-            PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups) {
+            const int nb = (int)std::min<size_t>(kMaxAggGroups, gs.size() - b);
+            if (d.kind == PEA_KIND_GCN) PEA_TRY(launch_aggregate(AGG_GCN, gs.data() + b, nb, stream));
+            else PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, gs.data() + b, nb, stream));
+        }
         return PEA_OK;
     }
     PEA_REQUIRE(phase == 0 || phase == 2, PEA_ERR_ARG, "backward: GAT/GCN levels have phases 0 and (sharded) 2");

@@ -95,6 +95,7 @@ class GraphPlan:
             for r in range(len(self.reverse_of), len(uniq)):
                 self.reverse_of.append(next(i for i, rr in enumerate(self.reverse_of) if rr == r))
         self.num_relations = len(uniq)
+        self._uniq = uniq
         ptrs = (C.c_void_p * len(uniq))(*[t.data_ptr() for t in uniq])
         nedge = (C.c_int64 * len(uniq))(*[t.shape[1] for t in uniq])
         handle = C.c_void_p()
@@ -141,6 +142,20 @@ class GraphPlan:
         names = ('edges', 'max_degree', 'short_rows', 'long_items', 'hub_rows', 'hub_chunks', 'rows_owned', 'edges_owned',
                  'slices')
         return dict(zip(names, [int(v) for v in info]))
+
+    def gcn_self_norm(self, r, from_col=False):
+        """float32 [N]: deg^-1 of GCNConv's normalisation under relation r (self loops dropped, one added per node; degree over
+        the source index -- PyG 1.5.0 -- or the target index): the weight dinv_i^2 of a node's own row, which is ALL of the
+        aggregate of a node without incoming edges.  Built once per relation and degree side."""
+        cache = self.__dict__.setdefault('_self_norm', {})
+        key = (r, bool(from_col))
+        if key not in cache:
+            ei = self._uniq[r]
+            keep = ei[0] != ei[1]
+            idx = ei[1 if from_col else 0][keep]
+            deg = torch.bincount(idx, minlength=self.num_nodes).to(torch.float32) + 1.0
+            cache[key] = (1.0 / deg).contiguous()
+        return cache[key]
 
     def edgeless_mask(self, r):
         """uint8 [N]: 1 where node n has no kept incoming edge under relation r (GAT / GCN: its conv output is its own
@@ -191,6 +206,7 @@ class PEAEngine:
         self._steps_c = (C.c_int * self.P)(*self.steps)
         self._rel_c = (C.c_int * len(flat))(*flat)
         self.enable_backward = bool(enable_backward)
+        self._gcn_from_col = gcn_deg_from == 'col'
         self._rev_c = None
         if self.enable_backward:
             if plan.reverse_of is None:
@@ -539,6 +555,7 @@ def grad_weight(pairs, shard=None, rows=None):
     for q, item in enumerate(pairs):
         a, b = _rows2d(item[0]), _rows2d(item[1])
         mask, alt = (item[2], _rows2d(item[3])) if len(item) > 2 else (None, None)     # rows flagged in mask read alt instead of b
+        alt_scale = item[4] if len(item) > 4 else None                                  # ... times alt_scale[row] (float32 [N])
         if a.shape[0] != n or b.shape[0] != n:
             raise ValueError('grad_weight: operands of one call must share the row count')
         out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=dev)
@@ -547,7 +564,8 @@ def grad_weight(pairs, shard=None, rows=None):
             raise ValueError('grad_weight: the row mask must be uint8 [N] and the alternative operand shaped like b')
         jobs[q] = _lib.GwJob(a.data_ptr(), a.stride(0), a.shape[1], b.data_ptr(), b.stride(0), b.shape[1],
                              out.data_ptr(), out.stride(0), None if mask is None else mask.data_ptr(),
-                             None if alt is None else alt.data_ptr(), 0 if alt is None else alt.stride(0))
+                             None if alt is None else alt.data_ptr(), 0 if alt is None else alt.stride(0),
+                             None if alt_scale is None else alt_scale.data_ptr())
     ws = _gw_ws.get(dev)
     if ws is None:
         ws = _gw_ws[dev] = torch.empty(int(lib.pea_grad_weight_workspace_bytes()), dtype=torch.uint8, device=dev)
@@ -598,7 +616,7 @@ def dense_batch(triples_, rows=None):
 _m2b_ws = {}
 
 
-def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da, rows=None):
+def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da, rows=None, weights_in_out=False):
     """Both products of the first layer's backward data path in one launch (csrc/mlp2_bwd.hip): for every channel
     (w0 [hid, emb], w1 [out, hid], dt1_col, h_col, dz_col, da_col) of `chans`:  dz = (dt1 . w1) where h > 0 else 0;
     da = dz . w0.  dt1, h, dz, da: float32 [N, ld] views of the training workspace.  rows (RowSet): the listed rows only."""
@@ -624,7 +642,7 @@ def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da, rows=None):
     _lib.check(lib.pea_mlp2_backward_data(n, len(chans), arr, int(emb), int(hid), int(out), _lib.ptr(dt1), dt1.stride(0),
                                           _lib.ptr(h), h.stride(0), _lib.ptr(dz), dz.stride(0), _lib.ptr(da), da.stride(0),
                                           None if rows is None else _lib.ptr(rows.ids), None if rows is None else _lib.ptr(rows.count),
-                                          _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+                                          1 if weights_in_out else 0, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
 
 
 def block_sum(src, n_blocks, width):

@@ -185,6 +185,7 @@ typedef struct pea_gw_job {
      * channel's first relation and x[n] itself where it has none (b = A_0 block, b_mask = the relation's edge-less flags,
      * b_alt = x) -- the x rows are never copied into A_0. */
     const unsigned char *b_mask; const float *b_alt; int64_t ldb_alt;
+    const float *b_alt_scale;   /* optional [rows]: the alternative row is multiplied by it (GCN: x[n] * deg^-1, the self-loop norm) */
 } pea_gw_job;
 typedef struct pea_dense_job {
     const float *a; int64_t lda; int k;
@@ -202,7 +203,8 @@ int pea_dense_batch(int64_t n_rows, int n_jobs, const pea_dense_job *jobs_host, 
  * (csrc/mlp2_bwd.hip) -- loss.backward() (solvers.py:215) through conv_1.lin -> F.relu -> conv_0.lin (models/base.py:138-139):
  *   dz[n, dz_col:+hid] = (dt1[n, dt1_col:+out] . w1)  where  h[n, h_col:+hid] > 0, else 0     (w1 = layer-2 lin.weight [out, hid])
  *   da[n, da_col:+emb] =  dz[n, ...] . w0                                                    (w0 = layer-1 lin.weight [hid, emb])
- * for every channel of the list; emb, hid in {64, 128}, out a multiple of 4 <= 32; all columns / strides multiples of 4. */
+ * for every channel of the list; emb, hid in {64, 128}, out a multiple of 4 <= 32; all columns / strides multiples of 4;
+ * weights_in_out = 1: the weights are laid out [in, out] (GCNConv.weight: w0 [emb, hid], w1 [hid, out]). */
 typedef struct pea_mlp2_bwd_chan {
     const float *w0, *w1;
     int dt1_col, h_col, dz_col, da_col;
@@ -210,8 +212,8 @@ typedef struct pea_mlp2_bwd_chan {
 size_t pea_mlp2_backward_data_workspace_bytes(int n_chan, int emb, int hid, int out);
 int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *chans_host, int emb, int hid, int out,
                            const float *dt1, int64_t ld_dt1, const float *h, int64_t ld_h, float *dz, int64_t ld_dz,
-                           float *da, int64_t ld_da, const int32_t *rows, const int32_t *count_dev, void *workspace,
-                           size_t workspace_bytes, void *stream);
+                           float *da, int64_t ld_da, const int32_t *rows, const int32_t *count_dev, int weights_in_out,
+                           void *workspace, size_t workspace_bytes, void *stream);
 /* Gradient support of a training step.  The loss reads the batch's rows only (models/base.py:46-48), so the input gradient of
  * the LAST conv layer is identically zero on every node that is neither a batch row nor an in-neighbour of one.
  *   pea_rows_nonzero     flags[n] = 1 where src[n, 0:width] holds a non-zero; list = the ids of those rows in ascending order,

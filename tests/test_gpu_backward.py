@@ -149,12 +149,12 @@ def test_conv_dropins_train_through_the_reference_channel_loop(kind, heads, aggr
         np.testing.assert_allclose(float(model.loss(bt)), float(loss), rtol=2e-5)
 
 
-@pytest.mark.parametrize('width', [64, 128])
-def test_two_step_training_schedule_matches_float64_and_the_levelwise_schedule(width, monkeypatch):
-    """GAT models of 2-step channels with emb == hidden in {64, 128} and one head train on the two-step schedule (csrc/model.h:
-    fused2_train): the first layer aggregates x, csrc/mlp2.hip chains both transforms (keeping the hidden tile), and the first
-    layer's backward runs in x space.  Every gradient against float64 autograd, and against the level-wise schedule
-    (PEA_FUSED2_TRAIN=0) on the same parameters; the model must really be on the two-step path."""
+@pytest.mark.parametrize('kind,width', [('gat', 64), ('gat', 128), ('gcn', 64), ('gcn', 128)])
+def test_two_step_training_schedule_matches_float64_and_the_levelwise_schedule(kind, width, monkeypatch):
+    """GAT (one head) and GCN models of 2-step channels with emb == hidden in {64, 128} train on the two-step schedule
+    (csrc/model.h: fused2_train): the first layer aggregates x, csrc/mlp2.hip chains both transforms (keeping the hidden tile),
+    and the first layer's backward runs in x space.  Every gradient against float64 autograd, and against the level-wise
+    schedule (PEA_FUSED2_TRAIN=0) on the same parameters; the model must really be on the two-step path."""
     n, blocks, rel = random_hin(47, n_user=1400, n_item=380, n_attr=25, e_u2i=18000, e_attr=1400)
     u2i, a2i = rel['u2i'], rel['a2i']
     flip = lambda e: np.ascontiguousarray(e[::-1])
@@ -167,7 +167,7 @@ def test_two_step_training_schedule_matches_float64_and_the_levelwise_schedule(w
     results = {}
     for mode in ('1', '0'):
         monkeypatch.setenv('PEA_FUSED2_TRAIN', mode)
-        model = build_model('gat', n, edges, steps, width, width, 16)
+        model = build_model(kind, n, edges, steps, width, width, 16)
         model.load_state_dict(random_state_dict(model, 12, scale=0.2))
         model.train()
         model.zero_grad()
@@ -180,7 +180,7 @@ def test_two_step_training_schedule_matches_float64_and_the_levelwise_schedule(w
             with torch.no_grad():               # the fused table left behind by the training forward
                 torch.testing.assert_close(model.cached_repr, model.forward(), rtol=1e-5, atol=1e-7)
             sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    want_loss, want = f64_loss_and_grads('gat', sd, edges, steps, 1, 'att', batch)
+    want_loss, want = f64_loss_and_grads(kind, sd, edges, steps, 1, 'att', batch)
     for mode, (loss, grads) in results.items():
         np.testing.assert_allclose(loss, want_loss, rtol=2e-5)
         g_max = max(np.abs(w).max() for w in want.values())
