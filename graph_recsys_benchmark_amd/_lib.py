@@ -60,6 +60,10 @@ class Mlp2BwdChan(C.Structure):
                 ('da_col', C.c_int)]
 
 
+class Mlp2BwdChanSage(C.Structure):
+    _fields_ = [('w0_root', C.c_void_p), ('w1_root', C.c_void_p), ('dr1_col', C.c_int), ('dxr_col', C.c_int)]
+
+
 class StageOpts(C.Structure):
     _fields_ = [('part', C.c_int), ('sel_ids', C.c_void_p), ('sel_stride', C.c_int64), ('n_sel', C.c_int64),
                 ('sel_out', C.c_void_p), ('err_flag', C.c_void_p)]
@@ -119,6 +123,10 @@ SIGNATURES = {
                                       _i64, _vp, _vp, _int, _vp, _sz, _vp]),
     'pea_rows_nonzero_workspace_bytes': (_sz, [_i64]),
     'pea_rows_nonzero': (_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pea_rows_nonzero_or': (_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pea_mlp2_backward_data_sage': (_int, [_i64, _int, C.POINTER(Mlp2BwdChan), C.POINTER(Mlp2BwdChanSage), _int, _int, _int,
+                                           _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz,
+                                           _vp]),
     'pea_grad_weight_rows': (_int, [_i64, _vp, _vp, _i64, _int, C.POINTER(GwJob), _vp, _sz, _vp]),
     'pea_model_set_active_rows0': (_int, [_vp, _vp, _vp, _vp]),
     'pea_rows_zero': (_int, [_vp, _i64, _int, _vp, _vp, _vp]),

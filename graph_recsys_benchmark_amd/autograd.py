@@ -19,7 +19,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import PARAM_SLOTS, RowSet, block_sum, dense_batch, grad_weight, mlp2_backward_data
+from .engine import PARAM_SLOTS, RowSet, block_sum, dense_batch, grad_weight, mlp2_backward_data, mlp2_backward_data_sage
 
 
 def _sparse_backward():
@@ -67,10 +67,11 @@ class _Slice:
         self.off, self.n, self.shape = off, n, shape
 
 
-def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compact=None):
+def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compact=None, batch_flags=None):
     """Gradients of sum(stack * d_stack) wrt x and every conv parameter.  Returns (dx, [tuple per layer]).
     compact = (ids, rows): d_stack given as the gradient rows [len(ids), P * R] of the stack rows `ids` (int64; duplicates
-    are summed in position order, ids < 0 skipped) instead of a dense [N, P, R] tensor (PEALossFunction)."""
+    are summed in position order, ids < 0 skipped) instead of a dense [N, P, R] tensor (PEALossFunction).
+    batch_flags (uint8 [N], optional): 1 on the rows of the stack that can carry a gradient."""
     lib = _lib.load()
     if not engine.enable_backward:
         raise RuntimeError('engine was built without enable_backward')
@@ -140,6 +141,85 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
         prev = lay.levels[s - 1] if s > 0 else None
         In_all = x if s == 0 else _view(wsf, prev['off_o'], n, prev['ld_o'])
         dIn_all = None if s == 0 else _view(wsf, prev['off_do'], n, max(prev['ld_o'], 4))
+        if kind == 'sage' and lay.two_step_train:
+            # Two-step training schedule, SAGE (csrc/model_bwd.hip, csrc/mlp2_bwd.hip; forward: mlp2_sage_kernel).  Layer 2 ran
+            # transform first: out = mean_j T_1[j] + R_1[i] with T_1 = H lin_rel1^T, R_1 = H lin_root1^T + bias1.
+            units = lv['units']
+            emb = x.shape[1]
+            if s == 1:
+                level_call(1, 0)     # d bias1 = colsum dX;  dT_1 = dX spread over the reversed relations (1 / deg_i each)
+                ncol = units[-1]['t_col'] + units[-1]['HF']
+                live = None
+                if _sparse_backward():
+                    # the rows whose hidden row received a gradient: in-neighbours of the batch's rows (dT_1) and, SAGE having
+                    # no self loops, the batch's rows themselves (the root term: dX)
+                    sets = getattr(engine, '_live_sets', None)
+                    if sets is None:
+                        sets = engine._live_sets = [RowSet(n, x.device), RowSet(n, x.device), 0, False]
+                    if batch_flags is None:
+                        aux = getattr(engine, '_aux_set', None)
+                        if aux is None:
+                            aux = engine._aux_set = RowSet(n, x.device)
+                        batch_flags = aux.fill_from(dX, ncol).flags
+                    sets[2] ^= 1
+                    live = sets[sets[2]].fill_from(dT, ncol, also=batch_flags)
+                engine._live_rows = live
+                pairs = []
+                for u in units:
+                    In = In_all[:, u['in_col']:u['in_col'] + u['in_w']]                    # the channel's hidden rows H
+                    pairs += [(dT[:, u['t_col']:u['t_col'] + u['HF']], In), (dX[:, u['o_col']:u['o_col'] + u['HF']], In)]
+                dWs = grad_weight(pairs, rows=live)
+                for q, u in enumerate(units):
+                    li = first[u['p']] + u['s']
+                    grads[li] = [dWs[2 * q], _Slice(lv['bias_off'] + u['t_col'], u['HF']), dWs[2 * q + 1]]
+                continue
+            nxt = lay.levels[1]
+            dT1 = _view(wsf, nxt['off_dt'], n, nxt['ld_t'])
+            H = _view(wsf, lv['off_o'], n, lv['ld_o'])
+            side = _view(wsf, lv['off_side'], n, lv['ld_t'])                               # the root term's gradient blocks
+            u1_of = {u1['p']: u1 for u1 in nxt['units']}
+            live = getattr(engine, '_live_rows', None)
+            if live is not None:
+                # invariant (as for GAT / GCN below): dM_0 and the root blocks are zero outside this step's list, so the
+                # reverse aggregation needs no per-row test
+                sets = engine._live_sets
+                if not sets[3]:
+                    dT.zero_()
+                    side.zero_()
+                    sets[3] = True
+                else:
+                    sets[1 - sets[2]].zero_rows_of(dT, len(units) * emb)
+                    sets[1 - sets[2]].zero_rows_of(side, len(units) * emb)
+            elif getattr(engine, '_live_sets', None) is not None:
+                engine._live_sets[3] = False
+            zeros = getattr(engine, '_zeros_n', None)
+            if zeros is None:
+                zeros = engine._zeros_n = torch.zeros(n, dtype=torch.float32, device=x.device)
+            chans, pairs = [], []
+            n_rel, prev_rel = 0, None
+            for u in units:
+                li = first[u['p']] + u['s']
+                c, u1 = u['t_col'], u1_of[u['p']]
+                if u['rel'] != prev_rel:           # one mean per distinct first relation, shared by its channels (model.hip)
+                    n_rel, prev_rel = n_rel + 1, u['rel']
+                a0 = (n_rel - 1) * emb
+                w_rel0, _b0, w_root0 = layer_params[li]
+                w_rel1, _b1, w_root1 = layer_params[li + 1]
+                chans.append((w_rel0, w_root0, w_rel1, w_root1, u1['t_col'], u1['o_col'], u['o_col'], c, c, c))
+                # d lin_rel0 = dZ_0^T M_0 (the mean of a row without incoming edges is 0: its stale A_0 row is swapped for
+                # 0 * x), d lin_root0 = dZ_0^T x
+                pairs += [(dO[:, c:c + u['HF']], T[:, a0:a0 + emb], plan.edgeless_mask(u['rel']), x, zeros),
+                          (dO[:, c:c + u['HF']], x)]
+            mlp2_backward_data_sage(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, dX, H, dO, dT, side, rows=live)
+            dWs = grad_weight(pairs, rows=live)
+            _lib.check(lib.pea_model_set_active_rows0(engine._h, None, None if live is None else _lib.ptr(live.ids),
+                                                      None if live is None else _lib.ptr(live.count)))
+            level_call(0, 0)          # d bias0; per channel: dM_0 spread over the reversed relation + the root block -> over A_0
+            dx = block_sum(T, len(units), emb)
+            for q, u in enumerate(units):
+                li = first[u['p']] + u['s']
+                grads[li] = [dWs[2 * q], _Slice(lv['bias_off'] + u['t_col'], u['HF']), dWs[2 * q + 1]]
+            continue
         if kind == 'sage':
             level_call(s, 0)
             dT.zero_()
@@ -475,7 +555,7 @@ class PEALossFunction(torch.autograd.Function):
         ctx.engine, ctx.n_slots, ctx.ids, ctx.ids_b = engine, n_slots, ids, ids_b
         ctx.grad_rows, ctx.head = grad_rows, head
         ctx.active_rows = None
-        if engine.kind == 'gat':
+        if engine.kind in ('gat', 'sage'):      # (SAGE: only the two-step training schedule reads them: the gradient's support)
             ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
             ctx.active_rows.index_fill_(0, ids, 1)
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
@@ -499,7 +579,8 @@ class PEALossFunction(torch.autograd.Function):
             # the conv stack's backward is linear in the batch's gradient rows: the upstream gradient scales them once
             # ([3B, P * R]) instead of every one of the ~80 parameter gradients afterwards
             try:
-                dx, grads = backward_conv_stack(ctx.engine, None, x, layer_params, ctx.ids, compact=(ctx.ids_b, ctx.grad_rows * g))
+                dx, grads = backward_conv_stack(ctx.engine, None, x, layer_params, ctx.ids, compact=(ctx.ids_b, ctx.grad_rows * g),
+                                                batch_flags=mask)
             finally:
                 if mask is not None:
                     _lib.check(lib.pea_model_set_active_rows(ctx.engine._h, None))

@@ -321,16 +321,21 @@ __global__ __launch_bounds__(512) void mlp2_sage_kernel(const Mlp2Launch L, cons
         f32x16 out;
 #pragma unroll
         for (int v = 0; v < 16; ++v) out[v] = 0.f;
+        // training (two-step training schedule): keep the hidden tile for the backward, same positions as mlp2_kernel<TRAIN>
+        float *hrow = (L.h0 && cur_valid) ? L.h0 + cur_row * L.ld_h0 + C.h0_col + 4 * half : nullptr;
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 w = ld4m(wt1 + ((size_t)(t * 4 + g) * 64 + lane) * 4);
                 const float4 bb = ld4m(b0p + t * 16 + 4 * g);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, fmaxf(acc[t][4 * g + 0] + bb.x, 0.f), out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, fmaxf(acc[t][4 * g + 1] + bb.y, 0.f), out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, fmaxf(acc[t][4 * g + 2] + bb.z, 0.f), out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, fmaxf(acc[t][4 * g + 3] + bb.w, 0.f), out, 0, 0, 0);
+                const float4 hv = make_float4(fmaxf(acc[t][4 * g + 0] + bb.x, 0.f), fmaxf(acc[t][4 * g + 1] + bb.y, 0.f),
+                                              fmaxf(acc[t][4 * g + 2] + bb.z, 0.f), fmaxf(acc[t][4 * g + 3] + bb.w, 0.f));
+                if (hrow) *reinterpret_cast<float4 *>(hrow + 32 * t + 8 * g) = hv;
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, hv.x, out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, hv.y, out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, hv.z, out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, hv.w, out, 0, 0, 0);
             }
         }
         if (cur_valid) {
@@ -423,6 +428,7 @@ static int launch_mlp2_v(Mlp2Launch L, const int *rows, int64_t n_rows, hipStrea
     const int grid = blocks;
     ProfScope ps("mlp2_fused", stream, 4.0 * (double)n_rows * (L.emb + (double)L.n * L.out * (SAGE ? 2 : 1)));
     if (SAGE) {
+        PEA_REQUIRE(L.h0 == nullptr || L.ld_h0 % 4 == 0, PEA_ERR_ARG, "mlp2: the training variant needs an aligned hidden table");
         PEA_LAUNCH((mlp2_sage_kernel<ET, HT>), dim3((unsigned)grid), dim3(kMlp2Threads), lds, stream, L, rows, n_rows);
     } else if (train) {
         PEA_REQUIRE(L.ld_h0 % 4 == 0, PEA_ERR_ARG, "mlp2: the training variant needs an aligned hidden table");

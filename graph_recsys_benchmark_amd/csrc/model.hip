@@ -57,8 +57,7 @@ int build_schedule(pea_model *m) {
     const int64_t N = plan->N;
     // SAGE: a model with training buffers keeps the reference's order (mean of the INPUT rows, then lin_rel on the mean:
     // the backward is written for it); without them it runs on the GAT/GCN schedule, see pea_model::sage2
-    m->sage2 = d.kind == PEA_KIND_SAGE && !m->backward;
-    const bool sage = d.kind == PEA_KIND_SAGE && !m->sage2, gat = d.kind == PEA_KIND_GAT;
+    // (two-step training schedule, fused2_train below: SAGE trains on the GAT/GCN schedule too -- mean and lin_rel commute)
     int Smax = 0;
     for (int p = 0; p < P; ++p) Smax = std::max(Smax, m->steps[(size_t)p]);
     {
@@ -71,12 +70,14 @@ int build_schedule(pea_model *m) {
         m->fused2 = all2 && !m->backward && !m->single_conv && (d.heads == 1 || d.kind != PEA_KIND_GAT) && P <= kMaxMlp2Chan &&
                     mlp2_supported(d.kind, d.emb_dim, d.hidden_size, d.repr_dim) && loops_ok && !(env && atoi(env) == 0);
         const char *envt = getenv("PEA_FUSED2_TRAIN");
-        m->fused2_train = all2 && m->backward && !m->single_conv && ((d.kind == PEA_KIND_GAT && d.heads == 1) || d.kind == PEA_KIND_GCN) &&
+        m->fused2_train = all2 && m->backward && !m->single_conv && (d.kind != PEA_KIND_GAT || d.heads == 1) &&
                           P <= kMaxMlp2Chan &&
                           mlp2_supported(d.kind, d.emb_dim, d.hidden_size, d.repr_dim) && loops_ok && d.emb_dim == d.hidden_size &&
                           plan->shard_world == 1 && !(envt && atoi(envt) == 0);
         m->ld_a0 = pad_ld(P * d.emb_dim);
     }
+    m->sage2 = d.kind == PEA_KIND_SAGE && (!m->backward || m->fused2_train);
+    const bool sage = d.kind == PEA_KIND_SAGE && !m->sage2, gat = d.kind == PEA_KIND_GAT;
     m->levels.assign((size_t)Smax, Level());
     std::vector<int> in_w((size_t)P, d.emb_dim), in_col((size_t)P, 0);
     int x_cols = 0;
@@ -353,7 +354,9 @@ int build_schedule(pea_model *m) {
             L.off_stats = off; off = pad_off(off + (size_t)N * (size_t)L.ld_stats);
             L.off_dt = off;    off = pad_off(off + (size_t)N * (size_t)L.ld_t);
             L.off_do = off;    off = pad_off(off + (size_t)N * (size_t)std::max(L.ld_o, 4));
-            L.off_side = off;  off = pad_off(off + (size_t)N * (size_t)std::max(L.ld_side, sage ? L.ld_t : 4));
+            // (SAGE on the two-step training schedule: the first level's side region holds the root-term gradient blocks)
+            const bool side_rows = sage || (m->fused2_train && d.kind == PEA_KIND_SAGE && &L == &m->levels[0]);
+            L.off_side = off;  off = pad_off(off + (size_t)N * (size_t)std::max(L.ld_side, side_rows ? L.ld_t : 4));
             L.off_dad = off;   off = pad_off(off + (size_t)N * (size_t)L.ld_k);
             L.off_das = off;   off = pad_off(off + (size_t)N * (size_t)L.ld_k);
             max_w = std::max(max_w, std::max(L.ld_t, L.ld_o));
@@ -901,6 +904,7 @@ int model_forward(pea_model *m, int stage, const float *const *params, const flo
                 C.a0_col = (n_rel - 1) * d.emb_dim;
                 C.t1_col = u1->t_col;
                 C.r1_col = u1->o_col;
+                C.h0_col = u.t_col;
                 C.deg0 = R.deg0;
                 PEA_TRY(set_exchange(C, *u1));
             }

@@ -115,6 +115,85 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
     const bool sharded = plan->shard_world > 1;
     const RowMap own = make_rowmap(N, plan->shard_tile, plan->shard_world, plan->shard_rank);
 
+    if (d.kind == PEA_KIND_SAGE && m->fused2_train) {
+        // Two-step training schedule, SAGE (forward: model.hip run_fused2_stage0 / mlp2_sage_kernel).  Layer 2 is transform
+        // first -- out = mean_j T_1[j] + R_1[i], T_1 = H lin_rel1^T, R_1 = H lin_root1^T + bias1 -- so its backward is a
+        // 16-wide gather:   level 1:  d bias1 = colsum dX;  dT_1[j] = sum_{i: j -> i} dX[i] / deg_i  (reversed relation).
+        // Level 0 (x space; the host mirror has run csrc/mlp2_bwd.hip: dZ_0 in dO_0, dM_0 = dZ_0 lin_rel0 per channel in the
+        // dT_0 region, the root term's gradient dZ_0 lin_root0 per channel in the side region):  d bias0 = colsum dZ_0 over
+        // the live rows;  per channel  dXp_j = sum_{i: j -> i} dM_0[i] / deg_i + (dZ_0 lin_root0)[j]  written over A_0 (dead
+        // once the weight gradients have read the means); the host sums the channel blocks into dx.
+        PEA_REQUIRE(phase == 0 && !sharded && level <= 1, PEA_ERR_ARG, "backward: the two-step training schedule is single-GPU, phase 0");
+        std::vector<AggGroup> gs;
+        if (level == 1) {
+            PEA_TRY(launch_colsum(own, L.n_cols, L.n_cols, dX, m->ld_x, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
+            for (const GroupPlan &g : L.groups) {
+                const int rr = m->reverse_of[(size_t)g.rel];
+                PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", g.rel);
+                PEA_REQUIRE(g.last && g.out_col == g.col, PEA_ERR_ARG, "backward: two-step SAGE expects X in the T_1 column order");
+                Relation &R = plan->rels[(size_t)g.rel], &Rr = plan->rels[(size_t)rr];
+                PEA_REQUIRE(g.partial_off + (size_t)std::max(R.n_slots, Rr.n_slots) * partial_record_floats(g.W, g.F) <= m->partial_floats,
+                            PEA_ERR_NOMEM, "backward: hub partial buffer too small for relation %d and its reverse", g.rel);
+                PEA_TRY(ensure_sage_arrays(plan, g.rel, stream));
+                AggGroup a{};
+                fill_lists(a, Rr);
+                a.W = g.W;
+                a.F = g.W;
+                a.feat = dX + g.out_col;
+                a.ld_feat = m->ld_x;
+                a.feat_self = a.feat;
+                a.ld_self = m->ld_x;
+                a.dinv = R.invdeg;           // 1 / max(deg_i, 1) of the gathered (forward destination) node
+                a.dinv_self = plan->ones;
+                a.out = dT + g.col;
+                a.ld_out = L.ld_t;
+                a.partial = partial + g.partial_off;
+                a.msgs_short = (double)Rr.edges_short;
+                a.msgs_long = (double)Rr.edges_long;
+                a.idx_share = 1.0;
+                a.table_rows = (double)Rr.src_span;
+                gs.push_back(a);
+            }
+        } else {
+            const int E0 = d.emb_dim;
+            const RowMap live = m->active0_list ? make_rowmap_list(N, m->active0_list, m->active0_count, N) : own;
+            PEA_TRY(launch_colsum(live, L.n_cols, L.n_cols, dO, L.ld_o, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
+            size_t part_off = 0;
+            for (size_t ui = 0; ui < L.units.size(); ++ui) {
+                const Unit &u = L.units[ui];
+                const int rr = m->reverse_of[(size_t)u.rel];
+                PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", u.rel);
+                Relation &R = plan->rels[(size_t)u.rel], &Rr = plan->rels[(size_t)rr];
+                const size_t rec = partial_record_floats(E0, E0);
+                PEA_REQUIRE(part_off + (size_t)std::max(R.n_slots, Rr.n_slots) * rec <= m->partial_floats, PEA_ERR_NOMEM,
+                            "backward: hub partial buffer too small for relation %d and its reverse", u.rel);
+                PEA_TRY(ensure_sage_arrays(plan, u.rel, stream));
+                AggGroup a{};
+                fill_lists(a, Rr);
+                a.W = E0;
+                a.F = E0;
+                a.self_loop = 1;             // the root term's gradient rides as the row's own term (weight 1)
+                a.partial = partial + part_off;
+                part_off += (size_t)std::max(R.n_slots, Rr.n_slots) * rec;
+                a.feat = dT + (size_t)ui * E0;
+                a.ld_feat = L.ld_t;
+                a.feat_self = wsf + L.off_side + (size_t)ui * E0;
+                a.ld_self = L.ld_t;
+                a.dinv = R.invdeg;
+                a.dinv_self = plan->ones;
+                a.out = T + (size_t)ui * E0;
+                a.ld_out = L.ld_t;
+                a.msgs_short = (double)Rr.edges_short;
+                a.msgs_long = (double)Rr.edges_long;
+                a.idx_share = 1.0;
+                a.table_rows = (double)Rr.src_span;
+                gs.push_back(a);
+            }
+        }
+        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
+            PEA_TRY(launch_aggregate(AGG_GCN, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        return PEA_OK;
+    }
     if (d.kind == PEA_KIND_SAGE) {
         PEA_REQUIRE(phase <= 1, PEA_ERR_ARG, "backward: SAGE levels have phases 0 and 1");
         if (phase == 0) {

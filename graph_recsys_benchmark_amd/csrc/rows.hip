@@ -15,6 +15,7 @@ namespace {
 
 // 8 lanes per row, float4 each: a lane group ORs its chunks, lane 0 of the group writes the flag
 __global__ __launch_bounds__(256) void row_nonzero_kernel(int64_t n_rows, int w4, const float *__restrict__ src, int64_t ld,
+                                                          const unsigned char *__restrict__ or_flags,
                                                           unsigned char *__restrict__ flags) {
     const int64_t row = (int64_t)blockIdx.x * 32 + threadIdx.x / 8;
     const int sl = threadIdx.x % 8;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void row_nonzero_kernel(int64_t n_rows, int w4
     any |= __shfl_xor(any, 1);
     any |= __shfl_xor(any, 2);
     any |= __shfl_xor(any, 4);
-    if (row < n_rows && sl == 0) flags[row] = (unsigned char)any;
+    if (row < n_rows && sl == 0) flags[row] = (unsigned char)((any || (or_flags && or_flags[row])) ? 1 : 0);
 }
 
 // table[list[q], 0:4*w4] = 0 for q < *count: 16 lanes x float4 per row piece, a fixed grid walking the list
@@ -60,13 +61,19 @@ extern "C" size_t pea_rows_nonzero_workspace_bytes(int64_t n_rows) {
 
 extern "C" int pea_rows_nonzero(int64_t n_rows, int width, const float *src, int64_t ld, unsigned char *flags, int32_t *list,
                                 int32_t *count_dev, void *workspace, size_t workspace_bytes, void *stream_) {
+    return pea_rows_nonzero_or(n_rows, width, src, ld, nullptr, flags, list, count_dev, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int pea_rows_nonzero_or(int64_t n_rows, int width, const float *src, int64_t ld, const unsigned char *or_flags,
+                                   unsigned char *flags, int32_t *list, int32_t *count_dev, void *workspace, size_t workspace_bytes,
+                                   void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PEA_REQUIRE(n_rows > 0 && n_rows < (int64_t)INT32_MAX && width > 0 && width % 4 == 0 && ld % 4 == 0 && ld >= width && src &&
-                    flags && list && count_dev && workspace, PEA_ERR_ARG, "rows_nonzero: bad argument");
+                    flags && list && count_dev && workspace && or_flags != flags, PEA_ERR_ARG, "rows_nonzero: bad argument");
     size_t temp = pea::select_temp_bytes(n_rows);
     PEA_REQUIRE(workspace_bytes >= temp + 256, PEA_ERR_NOMEM, "rows_nonzero: workspace too small");
     pea::ProfScope ps("rows_nonzero", stream, 4.0 * (double)n_rows * width);
-    PEA_LAUNCH(pea::row_nonzero_kernel, dim3((unsigned)((n_rows + 31) / 32)), dim3(256), 0, stream, n_rows, width / 4, src, ld, flags);
+    PEA_LAUNCH(pea::row_nonzero_kernel, dim3((unsigned)((n_rows + 31) / 32)), dim3(256), 0, stream, n_rows, width / 4, src, ld, or_flags, flags);
     PEA_HIP(hipGetLastError());
     void *tmp = aligned_ws(workspace);
     PEA_HIP(rocprim::select(tmp, temp, rocprim::counting_iterator<int>(0), (const unsigned char *)flags, list, count_dev,

@@ -531,12 +531,13 @@ class RowSet:
         _lib.check(_lib.load().pea_rows_zero(_lib.ptr(table), table.stride(0), int(width), _lib.ptr(self.ids), _lib.ptr(self.count),
                                              _lib.current_stream()))
 
-    def fill_from(self, table, width):
-        """flags / ids / count of the rows of table [N, ld] whose first `width` columns hold a non-zero."""
+    def fill_from(self, table, width, also=None):
+        """flags / ids / count of the rows of table [N, ld] whose first `width` columns hold a non-zero -- or that are flagged
+        in `also` (uint8 [N])."""
         table = _rows2d(table)
-        _lib.check(_lib.load().pea_rows_nonzero(self.n, int(width), _lib.ptr(table), table.stride(0), _lib.ptr(self.flags),
-                                                _lib.ptr(self.ids), _lib.ptr(self.count), _lib.ptr(self._ws), self._ws.numel(),
-                                                _lib.current_stream()))
+        _lib.check(_lib.load().pea_rows_nonzero_or(self.n, int(width), _lib.ptr(table), table.stride(0), _lib.ptr(also),
+                                                   _lib.ptr(self.flags), _lib.ptr(self.ids), _lib.ptr(self.count),
+                                                   _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
         return self
 
 
@@ -643,6 +644,35 @@ def mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da, rows=None, weights_
                                           _lib.ptr(h), h.stride(0), _lib.ptr(dz), dz.stride(0), _lib.ptr(da), da.stride(0),
                                           None if rows is None else _lib.ptr(rows.ids), None if rows is None else _lib.ptr(rows.count),
                                           1 if weights_in_out else 0, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+
+
+def mlp2_backward_data_sage(chans, emb, hid, out, dt1, dr1, h, dz, dm, dxr, rows=None):
+    """SAGE form of mlp2_backward_data (pea_mlp2_backward_data_sage): per channel (w_rel0 [hid, emb], w_root0, w_rel1 [out, hid],
+    w_root1, dt1_col, dr1_col, h_col, dz_col, dm_col, dxr_col):  dz = (dt1 . w_rel1 + dr1 . w_root1) where h > 0 else 0;
+    dm = dz . w_rel0;  dxr = dz . w_root0."""
+    lib = _lib.require_device()
+    n = dt1.shape[0]
+    arr = (_lib.Mlp2BwdChan * len(chans))()
+    arr_s = (_lib.Mlp2BwdChanSage * len(chans))()
+    keep = []
+    for q, (w0, w0r, w1, w1r, c1, cr, ch, cz, cm, cx) in enumerate(chans):
+        ws_ = [t.detach() if t.is_contiguous() else t.detach().contiguous() for t in (w0, w0r, w1, w1r)]
+        keep += ws_
+        arr[q] = _lib.Mlp2BwdChan(ws_[0].data_ptr(), ws_[2].data_ptr(), int(c1), int(ch), int(cz), int(cm))
+        arr_s[q] = _lib.Mlp2BwdChanSage(ws_[1].data_ptr(), ws_[3].data_ptr(), int(cr), int(cx))
+    need = int(lib.pea_mlp2_backward_data_workspace_bytes(len(chans), int(emb), int(hid), int(out)))
+    if need == 0:
+        raise ValueError('mlp2_backward_data_sage: unsupported widths (%d, %d, %d)' % (emb, hid, out))
+    key = (dt1.device, need)
+    ws = _m2b_ws.get(key)
+    if ws is None:
+        ws = _m2b_ws[key] = torch.empty(need, dtype=torch.uint8, device=dt1.device)
+    _lib.check(lib.pea_mlp2_backward_data_sage(n, len(chans), arr, arr_s, int(emb), int(hid), int(out), _lib.ptr(dt1), dt1.stride(0),
+                                               _lib.ptr(dr1), dr1.stride(0), _lib.ptr(h), h.stride(0), _lib.ptr(dz), dz.stride(0),
+                                               _lib.ptr(dm), dm.stride(0), _lib.ptr(dxr), dxr.stride(0),
+                                               None if rows is None else _lib.ptr(rows.ids),
+                                               None if rows is None else _lib.ptr(rows.count), _lib.ptr(ws), ws.numel(),
+                                               _lib.current_stream()))
 
 
 def block_sum(src, n_blocks, width):

@@ -214,6 +214,21 @@ int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *
                            const float *dt1, int64_t ld_dt1, const float *h, int64_t ld_h, float *dz, int64_t ld_dz,
                            float *da, int64_t ld_da, const int32_t *rows, const int32_t *count_dev, int weights_in_out,
                            void *workspace, size_t workspace_bytes, void *stream);
+/* The same for SAGEConv layers (lin_rel / lin_root, both [out, in]; out <= 16): the hidden row feeds two second-layer products
+ * and is fed by two first-layer ones (nn SAGEConv: lin_rel(mean_j x_j) + lin_root(x_i), models/base.py:138-139):
+ *   dz[n, dz_col:+hid]   = (dt1[n, dt1_col:+out] . w1 + dr1[n, dr1_col:+out] . w1_root)  where  h > 0, else 0
+ *   dm[n, da_col:+emb]   =  dz . w0          gradient of the neighbour mean (still to be spread over the reversed relation)
+ *   dxr[n, dxr_col:+emb] =  dz . w0_root     gradient of the row's own x through the root term
+ * chans_host[c] carries lin_rel of both layers and the shared columns, sage_host[c] the root weights and their columns. */
+typedef struct pea_mlp2_bwd_chan_sage {
+    const float *w0_root, *w1_root;
+    int dr1_col, dxr_col;
+} pea_mlp2_bwd_chan_sage;
+int pea_mlp2_backward_data_sage(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *chans_host,
+                                const pea_mlp2_bwd_chan_sage *sage_host, int emb, int hid, int out, const float *dt1,
+                                int64_t ld_dt1, const float *dr1, int64_t ld_dr1, const float *h, int64_t ld_h, float *dz,
+                                int64_t ld_dz, float *dm, int64_t ld_dm, float *dxr, int64_t ld_dxr, const int32_t *rows,
+                                const int32_t *count_dev, void *workspace, size_t workspace_bytes, void *stream);
 /* Gradient support of a training step.  The loss reads the batch's rows only (models/base.py:46-48), so the input gradient of
  * the LAST conv layer is identically zero on every node that is neither a batch row nor an in-neighbour of one.
  *   pea_rows_nonzero     flags[n] = 1 where src[n, 0:width] holds a non-zero; list = the ids of those rows in ascending order,
@@ -226,6 +241,11 @@ int pea_mlp2_backward_data(int64_t n_rows, int n_chan, const pea_mlp2_bwd_chan *
 size_t pea_rows_nonzero_workspace_bytes(int64_t n_rows);
 int pea_rows_nonzero(int64_t n_rows, int width, const float *src, int64_t ld, unsigned char *flags, int32_t *list,
                      int32_t *count_dev, void *workspace, size_t workspace_bytes, void *stream);
+/* ... or flagged in or_flags [n_rows] (may be NULL; must not alias flags): SAGE has no self loops, so the batch's own rows (which
+ * receive the root term's gradient) are not among the rows the last layer's gradient gathers reach -- the caller adds them */
+int pea_rows_nonzero_or(int64_t n_rows, int width, const float *src, int64_t ld, const unsigned char *or_flags,
+                        unsigned char *flags, int32_t *list, int32_t *count_dev, void *workspace, size_t workspace_bytes,
+                        void *stream);
 int pea_grad_weight_rows(int64_t num_rows, const int32_t *rows, const int32_t *count_dev, int64_t capacity, int n_jobs,
                          const pea_gw_job *jobs_host, void *workspace, size_t workspace_bytes, void *stream);
 int pea_model_set_active_rows0(pea_model *model, const unsigned char *flags, const int32_t *list, const int32_t *count_dev);

@@ -149,9 +149,9 @@ def test_conv_dropins_train_through_the_reference_channel_loop(kind, heads, aggr
         np.testing.assert_allclose(float(model.loss(bt)), float(loss), rtol=2e-5)
 
 
-@pytest.mark.parametrize('kind,width', [('gat', 64), ('gat', 128), ('gcn', 64), ('gcn', 128)])
+@pytest.mark.parametrize('kind,width', [('gat', 64), ('gat', 128), ('gcn', 64), ('gcn', 128), ('sage', 64), ('sage', 128)])
 def test_two_step_training_schedule_matches_float64_and_the_levelwise_schedule(kind, width, monkeypatch):
-    """GAT (one head) and GCN models of 2-step channels with emb == hidden in {64, 128} train on the two-step schedule
+    """GAT (one head), GCN and SAGE models of 2-step channels with emb == hidden in {64, 128} train on the two-step schedule
     (csrc/model.h: fused2_train): the first layer aggregates x, csrc/mlp2.hip chains both transforms (keeping the hidden tile),
     and the first layer's backward runs in x space.  Every gradient against float64 autograd, and against the level-wise
     schedule (PEA_FUSED2_TRAIN=0) on the same parameters; the model must really be on the two-step path."""
