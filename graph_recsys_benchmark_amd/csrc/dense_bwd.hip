@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace pea {
@@ -17,8 +19,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGwParts = 128;     // row parts per job (grid.x)
-constexpr int kGwMaxJobs = 16;    // 64x64 blocks per launch
+constexpr int kGwRecords = 4096;  // (job, part) records of 16 x 256 floats in the workspace
+constexpr int kGwMaxJobs = 40;    // 64x64 blocks per launch (the job table travels as a kernel argument: < 4 KB)
+constexpr int kGwMaxParts = 512;  // row parts per job (grid.x), chosen per launch: gw_parts()
 struct GwJob {
     const float *a, *b;
     const unsigned char *b_mask;   // optional [rows]: rows flagged here take their b operand from b_alt (pea_gw_job)
@@ -40,10 +43,13 @@ template <int MT, int NT>
 __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
     const int64_t n_rows = M.size();   // sharded plans reduce over the rows this rank owns (RowMap), else over all rows
     __shared__ float red[3][MT * NT * 256];
-    const GwJob &J = Jb.j[blockIdx.y];
+    // grid (jobs, parts): the workgroups of one row part -- they read neighbouring column blocks of the SAME rows -- are
+    // dispatched together
+    const int job = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+    const GwJob &J = Jb.j[job];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int64_t chunk = ((n_rows + kGwParts - 1) / kGwParts + 15) / 16 * 16;
-    const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = min(n_rows, r0 + chunk);
+    const int64_t chunk = ((n_rows + parts - 1) / parts + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)part * chunk, r1 = min(n_rows, r0 + chunk);
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
     }
     __syncthreads();
     if (wave == 0) {
-        float *dst = partial + ((size_t)blockIdx.y * kGwParts + blockIdx.x) * (MT * NT * 256);
+        float *dst = partial + ((size_t)job * parts + part) * (MT * NT * 256);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -111,37 +117,41 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
 // added in the same order as above within a part (the k index of the MFMA steps runs over the rows in order), so the
 // results agree with the dword version bit for bit per tile... up to which wave owned which rows there: that version
 // summed four interleaved row subsets and added them; this one adds all rows of the part in order.
-constexpr int kGwLd = 80;
+constexpr int kGwLd = 72;   // row stride of the LDS images: lanes (kq, i) of an operand read land two per bank (the minimum
+                            // for 64 lanes), and 36 KB per workgroup lets FOUR of them share a CU (80: 41 KB, three)
 __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
     const int64_t n_rows = M.size();
     __shared__ float As[2][32][kGwLd], Bs[2][32][kGwLd];
-    const GwJob &J = Jb.j[blockIdx.y];
+    const int job = blockIdx.x, part = blockIdx.y, parts = gridDim.y;   // (see gw_stage1)
+    const GwJob &J = Jb.j[job];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int64_t chunk = ((n_rows + kGwParts - 1) / kGwParts + 15) / 16 * 16;
-    const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = min(n_rows, r0 + chunk);
+    const int64_t chunk = ((n_rows + parts - 1) / parts + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)part * chunk, r1 = min(n_rows, r0 + chunk);
     f32x4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // loader role: thread t moves float4 column (t % 16) of rows (t / 16) and (t / 16) + 16 of the chunk, both operands
+    // loader role: thread t moves float4 column (t % 16) of rows (t / 16) and (t / 16) + 16 of a 32-row chunk, both operands.
+    // Software pipeline, per chunk c: row ids + operand flags (c - 3 .. c - 2: one step ahead of the loads they steer -- a
+    // flag or a listed row id read in the same step sat in front of every operand load: 0.56 -> 0.84 ms on the nine
+    // first-layer blocks of the 25m-shaped graph), global loads into one of TWO register sets (issued while chunk c - 2 is
+    // multiplied), LDS store after chunk c - 1's products, products.  (Two chunks of loads in flight and four workgroups per
+    // CU instead of one and three: measured, no change -- 0.122 ms for nine blocks over 72 k listed rows either way: the
+    // kernel is not waiting on latency; its operand pieces are 256 bytes of 2304-byte rows.)
     const int lr = tid >> 4, lc = (tid & 15) * 4;
-    float4 pa[2], pb[2];
-    // row flags of the b operand (pea_gw_job::b_mask) are read one chunk AHEAD of the rows they steer: read in the same
-    // step, the flag load sat in front of every operand load (a dependent load per row: 0.56 -> 0.84 ms on the nine
-    // first-layer blocks of the 25m-shaped graph)
-    // (so are the row ids of a listed row set: list[q] would otherwise sit in front of both operand loads)
-    unsigned char fl[2] = {0, 0}, fl_next[2] = {0, 0};
-    int64_t rid[2] = {-1, -1}, rid_next[2] = {-1, -1};      // -1: past the end of the part
-    auto flags = [&](int64_t base, unsigned char (&f)[2], int64_t (&id)[2]) {
+    float4 pa[2][2], pb[2][2];
+    unsigned char fl[2] = {0, 0};
+    int64_t rid[2] = {-1, -1};      // -1: past the end of the part
+    auto flags = [&](int64_t base) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t n = base + lr + 16 * u;
             const int64_t nr = n < r1 ? M.row(n) : -1;
             const bool ok = nr >= 0 && nr < M.N;
-            id[u] = ok ? nr : -1;
-            f[u] = (J.b_mask && ok) ? J.b_mask[nr] : (unsigned char)0;
+            rid[u] = ok ? nr : -1;
+            fl[u] = (J.b_mask && ok) ? J.b_mask[nr] : (unsigned char)0;
         }
     };
-    auto fetch = [&](int64_t base) {
+    auto fetch = [&](int set) {     // the chunk whose ids / flags are current
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bool ok = rid[u] >= 0;
@@ -152,44 +162,49 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
                 const float bs = J.b_alt_scale[nc];
                 vb = make_float4(bs * vb.x, bs * vb.y, bs * vb.z, bs * vb.w);
             }
-            pa[u] = ok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
-            pb[u] = ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+            pa[set][u] = ok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[set][u] = ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int set, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<float4 *>(&As[buf][lr + 16 * u][lc]) = pa[u];
-            *reinterpret_cast<float4 *>(&Bs[buf][lr + 16 * u][lc]) = pb[u];
+            *reinterpret_cast<float4 *>(&As[buf][lr + 16 * u][lc]) = pa[set][u];
+            *reinterpret_cast<float4 *>(&Bs[buf][lr + 16 * u][lc]) = pb[set][u];
         }
     };
     if (r0 < r1) {
-        flags(r0, fl, rid);
-        fetch(r0);
-        stash(0);
-        flags(r0 + 32, fl, rid);
+        flags(r0);
+        fetch(0);                 // chunk 0
+        flags(r0 + 32);
+        stash(0, 0);
+        fetch(1);                 // chunk 1 (zeros past the end)
+        flags(r0 + 64);           // ids of chunk 2
     }
-    int buf = 0;
-    for (int64_t base = r0; base < r1; base += 32, buf ^= 1) {
-        __syncthreads();
-        if (base + 32 < r1) {
-            fetch(base + 32);            // steered by the row ids / flags read an iteration ago
-            flags(base + 64, fl_next, rid_next);
-            fl[0] = fl_next[0];
-            fl[1] = fl_next[1];
-            rid[0] = rid_next[0];
-            rid[1] = rid_next[1];
+    // (two chunks per trip so that the register set / LDS image indices are compile-time constants: indexed by a
+    // run-time parity the register sets went to scratch memory)
+    auto step = [&](auto CUR, int64_t base) {
+        constexpr int cur = decltype(CUR)::value;
+        __syncthreads();          // LDS image `cur` is complete; image cur ^ 1 is free (its products ended an iteration ago)
+        const bool more1 = base + 32 < r1, more2 = base + 64 < r1;
+        if (more2) {
+            fetch(cur);           // chunk it + 2 -> register set (it & 1): chunk it's registers went to LDS an iteration ago
+            flags(base + 96);     // ids of chunk it + 3
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const float av = As[buf][4 * s + kq][16 * wave + i];
+            const float av = As[cur][4 * s + kq][16 * wave + i];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[buf][4 * s + kq][16 * nt + i], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[cur][4 * s + kq][16 * nt + i], acc[nt], 0, 0, 0);
         }
-        if (base + 32 < r1) stash(buf ^ 1);
+        if (more1) stash(cur ^ 1, cur ^ 1);   // chunk it + 1, loaded while chunks it - 1 and it were multiplied
+    };
+    for (int64_t base = r0; base < r1; base += 64) {
+        step(std::integral_constant<int, 0>(), base);
+        if (base + 32 < r1) step(std::integral_constant<int, 1>(), base + 32);
     }
-    float *dst = partial + ((size_t)blockIdx.y * kGwParts + blockIdx.x) * (16 * 256);
+    float *dst = partial + ((size_t)job * parts + part) * (16 * 256);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -199,36 +214,70 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
 // stage 2: out = sum over parts, part order.  Element e of a record: tile (mt, nt), register v, lane l ->
 // row 16 mt + 4 (l / 16) + v, column 16 nt + l % 16.
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void gw_stage2(const GwBatch Jb, const float *__restrict__ partial) {
+__global__ __launch_bounds__(256) void gw_stage2(const GwBatch Jb, const float *__restrict__ partial, int parts) {
+    // 64 elements per workgroup; quarter q of the threads adds parts q, q + 4, ... of its element in order, then the four
+    // sub-sums are added in order (fixed order; one chain of `parts` dependent loads per element took as long as stage 1
+    // on the listed-row launches)
+    __shared__ float sub[3][64];
     const GwJob &J = Jb.j[blockIdx.y];
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= MT * NT * 256) return;
-    const float *src = partial + (size_t)blockIdx.y * kGwParts * (MT * NT * 256) + e;
+    const int q = threadIdx.x >> 6, e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float *src = partial + (size_t)blockIdx.y * parts * (MT * NT * 256) + e;
     float s = 0.f;
-    for (int p = 0; p < kGwParts; ++p) s += src[(size_t)p * (MT * NT * 256)];
+    for (int p = q; p < parts; p += 4) s += src[(size_t)p * (MT * NT * 256)];
+    if (q > 0) sub[q - 1][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q > 0) return;
+    s = ((s + sub[0][threadIdx.x]) + sub[1][threadIdx.x]) + sub[2][threadIdx.x];
     const int lane = e & 63, v = (e >> 6) & 3, t = e >> 8, mt = t / NT, nt = t % NT;
     const int row = 16 * mt + 4 * (lane >> 4) + v, col = 16 * nt + (lane & 15);
     if (row < J.ma && col < J.nb) J.out[(int64_t)row * J.ldo + col] = s;
 }
 
+// Row parts per job of one launch: (jobs x parts) = one round of resident workgroups for the LDS-staged kernel (four per CU),
+// two for the dword kernel, each part keeping at least ~256 rows where the row count allows.  Measured on the 25m-shaped
+// shapes (profiles/tools/gw_bench.py, profiles/r03/gw_bench_r03.txt): between 43 and 227 parts stage 1 moves within
+// +-15 % (2.7-3.9 TB/s of operand bytes: 256-byte pieces of 2304-byte rows), while stage 2 grows with the part count.
+// PEA_GW_PARTS overrides (experiments).
+int gw_parts(int n_jobs, int64_t n_rows, bool lds_kernel) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const char *env = getenv("PEA_GW_PARTS");
+    int parts;
+    if (env && atoi(env) > 0) {
+        parts = atoi(env);
+    } else {
+        const int round = std::max(1, (lds_kernel ? 4 : 3) * n_cu / n_jobs);    // parts of one resident round
+        const int64_t fit = std::max<int64_t>(1, n_rows / 256);                  // parts that still hold ~256 rows
+        const int rounds = lds_kernel ? 1 : 2;
+        parts = (int)std::min<int64_t>((int64_t)round * rounds, std::max<int64_t>(fit, 8));
+    }
+    return std::max(1, std::min(std::min(parts, kGwMaxParts), kGwRecords / n_jobs));
+}
+
 template <int MT, int NT>
-int launch_gw(const GwBatch &Jb, const RowMap &rows, float *partial, double bytes, hipStream_t stream) {
+int launch_gw(const GwBatch &Jb, const RowMap &rows, float *partial, double bytes, int64_t n_rows, hipStream_t stream) {
+    bool full = MT == 4 && NT == 4;   // every block 64 x 64 with float4-addressable operands: the LDS-staged kernel
+    for (int q = 0; q < Jb.n && full; ++q)
+        full = Jb.j[q].ma == 64 && Jb.j[q].nb == 64 && Jb.j[q].lda % 4 == 0 && Jb.j[q].ldb % 4 == 0 &&
+               (reinterpret_cast<uintptr_t>(Jb.j[q].a) | reinterpret_cast<uintptr_t>(Jb.j[q].b)) % 16 == 0 &&
+               (!Jb.j[q].b_mask || (Jb.j[q].ldb_alt % 4 == 0 && reinterpret_cast<uintptr_t>(Jb.j[q].b_alt) % 16 == 0));
+    const int parts = gw_parts(Jb.n, n_rows, full);
     {
         ProfScope ps("grad_weight", stream, bytes);
-        bool full = MT == 4 && NT == 4;   // every block 64 x 64 with float4-addressable operands: the LDS-staged kernel
-        for (int q = 0; q < Jb.n && full; ++q)
-            full = Jb.j[q].ma == 64 && Jb.j[q].nb == 64 && Jb.j[q].lda % 4 == 0 && Jb.j[q].ldb % 4 == 0 &&
-                   (reinterpret_cast<uintptr_t>(Jb.j[q].a) | reinterpret_cast<uintptr_t>(Jb.j[q].b)) % 16 == 0 &&
-                   (!Jb.j[q].b_mask || (Jb.j[q].ldb_alt % 4 == 0 && reinterpret_cast<uintptr_t>(Jb.j[q].b_alt) % 16 == 0));
         if (full) {
-            PEA_LAUNCH(gw_stage1_lds, dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
+            PEA_LAUNCH(gw_stage1_lds, dim3((unsigned)Jb.n, (unsigned)parts), dim3(256), 0, stream, Jb, rows, partial);
         } else {
-            PEA_LAUNCH((gw_stage1<MT, NT>), dim3(kGwParts, (unsigned)Jb.n), dim3(256), 0, stream, Jb, rows, partial);
+            PEA_LAUNCH((gw_stage1<MT, NT>), dim3((unsigned)Jb.n, (unsigned)parts), dim3(256), 0, stream, Jb, rows, partial);
         }
         PEA_HIP(hipGetLastError());
     }
     ProfScope ps("grad_weight_sum", stream);
-    PEA_LAUNCH((gw_stage2<MT, NT>), dim3(MT * NT, (unsigned)Jb.n), dim3(256), 0, stream, Jb, partial);
+    PEA_LAUNCH((gw_stage2<MT, NT>), dim3(MT * NT * 4, (unsigned)Jb.n), dim3(256), 0, stream, Jb, partial, parts);
     PEA_HIP(hipGetLastError());
     return PEA_OK;
 }
@@ -241,7 +290,7 @@ int tiles_of(int w) { return w <= 16 ? 1 : w <= 32 ? 2 : 4; }
 using namespace pea;
 
 extern "C" size_t pea_grad_weight_workspace_bytes(void) {
-    return (size_t)kGwMaxJobs * kGwParts * 16 * 256 * sizeof(float) + 256;
+    return (size_t)kGwRecords * 16 * 256 * sizeof(float) + 256;
 }
 
 extern "C" int pea_grad_weight_sharded(int64_t n_rows, int shard_tile, int shard_world, int shard_rank, int n_jobs,
@@ -318,15 +367,15 @@ static int grad_weight_impl(const pea::RowMap &rowmap, int64_t n_rows, int n_job
                 hipStream_t st = (hipStream_t)stream;
                 int rc = PEA_OK;
                 switch (a * 3 + b) {
-                    case 0: rc = launch_gw<1, 1>(Jb, rowmap, partial, bytes, st); break;
-                    case 1: rc = launch_gw<1, 2>(Jb, rowmap, partial, bytes, st); break;
-                    case 2: rc = launch_gw<1, 4>(Jb, rowmap, partial, bytes, st); break;
-                    case 3: rc = launch_gw<2, 1>(Jb, rowmap, partial, bytes, st); break;
-                    case 4: rc = launch_gw<2, 2>(Jb, rowmap, partial, bytes, st); break;
-                    case 5: rc = launch_gw<2, 4>(Jb, rowmap, partial, bytes, st); break;
-                    case 6: rc = launch_gw<4, 1>(Jb, rowmap, partial, bytes, st); break;
-                    case 7: rc = launch_gw<4, 2>(Jb, rowmap, partial, bytes, st); break;
-                    default: rc = launch_gw<4, 4>(Jb, rowmap, partial, bytes, st); break;
+                    case 0: rc = launch_gw<1, 1>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    case 1: rc = launch_gw<1, 2>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    case 2: rc = launch_gw<1, 4>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    case 3: rc = launch_gw<2, 1>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    case 4: rc = launch_gw<2, 2>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    case 5: rc = launch_gw<2, 4>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    case 6: rc = launch_gw<4, 1>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    case 7: rc = launch_gw<4, 2>(Jb, rowmap, partial, bytes, n_rows, st); break;
+                    default: rc = launch_gw<4, 4>(Jb, rowmap, partial, bytes, n_rows, st); break;
                 }
                 PEA_TRY(rc);
             }
