@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void gw_stage2(const GwBatch Jb, const float *
     const int q = threadIdx.x >> 6, e = blockIdx.x * 64 + (threadIdx.x & 63);
     const float *src = partial + (size_t)blockIdx.y * parts * (MT * NT * 256) + e;
     float s = 0.f;
+#pragma unroll 8                 // the loads of eight parts in flight; the adds stay in part order
     for (int p = q; p < parts; p += 4) s += src[(size_t)p * (MT * NT * 256)];
     if (q > 0) sub[q - 1][threadIdx.x & 63] = s;
     __syncthreads();

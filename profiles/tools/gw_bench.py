@@ -59,7 +59,9 @@ def main():
     lvl0 = [(dz[:, c * w:(c + 1) * w], a0[:, c * w:(c + 1) * w], mask, x) for c in range(p)]
     lvl0_sage = lvl0 + [(dz[:, c * w:(c + 1) * w], x) for c in range(p)]
     lvl1 = [(dt1[:, c * out:(c + 1) * out], dz[:, c * w:(c + 1) * w]) for c in range(p)]
-    for name, pairs in (('level 0 (%d x [%d, %d], masked operand)' % (p, w, w), lvl0),
+    das = torch.randn(n, 12, device=dev)
+    att = [(das, x), (das, x)]
+    for name, pairs in (('att (2 x [12, %d], all rows are live)' % w, att), ('level 0 (%d x [%d, %d], masked operand)' % (p, w, w), lvl0),
                         ('level 0 SAGE (%d x [%d, %d])' % (2 * p, w, w), lvl0_sage),
                         ('level 1 (%d x [%d, %d])' % (p, out, w), lvl1), ('level 1 SAGE (%d x [%d, %d])' % (2 * p, out, w), lvl1 + lvl1)):
         t_list, s_list = timed(lambda: grad_weight(pairs, rows=live))

@@ -50,4 +50,10 @@ def test_loss_goes_down_and_matches_the_torch_head(kind, aggr):
         ref = _train(model2, batch, 6)
     finally:
         engine.bpr_train_supported = orig
-    np.testing.assert_allclose(hip[:6], ref, rtol=2e-4)
+    # The first two steps see the same parameters up to one rounding of the gradients: tight.  After that Adam has divided
+    # rounding noise by sqrt(v) (an entry whose gradient is noise still moves by ~lr per step), and at this learning rate
+    # the GCN loss swings 282 -> 181 -> 265: the SAME path re-run with only the fp32 summation order of the weight-gradient
+    # reduction changed (PEA_GW_PARTS=64 vs 128, profiles/tools/adam_sensitivity.py, profiles/r03/adam_sensitivity_r03.txt)
+    # is 9e-6 apart at step 3, 1.9e-4 at step 5 and 2.6e-4 at step 6.  The later steps are therefore held to 2e-3.
+    np.testing.assert_allclose(hip[:2], ref[:2], rtol=2e-5)
+    np.testing.assert_allclose(hip[2:6], ref[2:6], rtol=2e-3)
