@@ -491,7 +491,7 @@ class PEAStackFunction(torch.autograd.Function):
                                               train=True, gather=False)
         ctx.engine, ctx.n_slots = engine, n_slots
         ctx.active_ids, ctx.active_rows = options.read_ids, None
-        if options.read_ids is not None and engine.kind == 'gat':
+        if options.read_ids is not None:      # (every kind: the last layer's gradient gathers skip the rows not flagged)
             ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
             ctx.active_rows.index_fill_(0, options.read_ids, 1)      # (indexed assignment of a Python scalar stages it through the host)
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
@@ -555,9 +555,10 @@ class PEALossFunction(torch.autograd.Function):
         ctx.engine, ctx.n_slots, ctx.ids, ctx.ids_b = engine, n_slots, ids, ids_b
         ctx.grad_rows, ctx.head = grad_rows, head
         ctx.active_rows = None
-        if engine.kind in ('gat', 'sage'):      # (SAGE: only the two-step training schedule reads them: the gradient's support)
-            ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
-            ctx.active_rows.index_fill_(0, ids, 1)
+        # the batch's rows: the only rows of the last layer's output gradient that are non-zero (GAT: D / S passes; GCN and
+        # SAGE: the reverse aggregation does not fetch the others; two-step SAGE: part of the gradient's support)
+        ctx.active_rows = torch.zeros(x.shape[0], dtype=torch.uint8, device=x.device)
+        ctx.active_rows.index_fill_(0, ids, 1)
         ctx.save_for_backward(x, *[t for t in flat if t is not None])
         ctx.present = [t is not None for t in flat]
         return loss

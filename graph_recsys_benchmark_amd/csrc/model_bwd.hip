@@ -127,6 +127,13 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         std::vector<AggGroup> gs;
         if (level == 1) {
             PEA_TRY(launch_colsum(own, L.n_cols, L.n_cols, dX, m->ld_x, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
+            const unsigned *active_bits = nullptr;
+            if (m->active_rows) {   // only the batch's rows of dX are non-zero: the others are not fetched (csrc/agg.hip)
+                if (!m->active_bits) PEA_HIP(hipMalloc((void **)&m->active_bits, (size_t)((N + 63) / 64) * 2 * sizeof(unsigned)));
+                PEA_LAUNCH(flags_to_bits_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, m->active_rows, m->active_bits);
+                PEA_HIP(hipGetLastError());
+                active_bits = m->active_bits;
+            }
             for (const GroupPlan &g : L.groups) {
                 const int rr = m->reverse_of[(size_t)g.rel];
                 PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", g.rel);
@@ -145,6 +152,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
                 a.ld_self = m->ld_x;
                 a.dinv = R.invdeg;           // 1 / max(deg_i, 1) of the gathered (forward destination) node
                 a.dinv_self = plan->ones;
+                a.row_active_bits = active_bits;
                 a.out = dT + g.col;
                 a.ld_out = L.ld_t;
                 a.partial = partial + g.partial_off;
@@ -365,7 +373,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         }
     }
     const unsigned *active_bits = nullptr;
-    if (d.kind == PEA_KIND_GAT && m->active_rows && part_b) {
+    if (m->active_rows && part_b) {   // (GCN: the reverse aggregation skips the gathered rows known to be zero, csrc/agg.hip)
         bool any_last = false;
         for (const GroupPlan &g : L.groups) any_last = any_last || g.last;
         if (any_last) {   // the S pass tests one flag per gathered row: as a bitmap the flags of all nodes fit a CU's L1
@@ -403,6 +411,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             a.dinv_self = a.dinv;
             a.out = dT + g.col;
             a.ld_out = L.ld_t;
+            a.row_active_bits = g.last ? active_bits : nullptr;   // only the batch's rows of dX are non-zero
             if (part_b) gsrc.push_back(a);
             continue;
         }
