@@ -127,6 +127,29 @@ __device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk)
     const int k = c4 / P.F;
     int len = end - beg;
     for (int off = G; off < kWave; off <<= 1) len = max(len, __shfl_xor(len, off));  // head sums are cross-lane
+    if (MODE == AGG_SUM_BWD_S) {
+        const float di = P.dinv_self[row];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int U = 4;
+        for (int t = 0; t < len; t += U) {
+            bool ok[U];
+            int ii[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = beg + t + u < end;
+                ii[u] = ok[u] ? P.col[beg + t + u] : 0;
+                if (P.row_active && ok[u] && !row_live(P, ii[u])) ok[u] = false, ii[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;                       // rows known to be zero are not fetched
+                acc = fma4(P.dinv[ii[u]], ld4(row_at(P.feat + c4, ii[u], P.ld_feat)), acc);
+            }
+        }
+        if (P.self_loop && row_on) acc = fma4(di, ld4(row_at(P.feat_self + c4, row, P.ld_self)), acc);
+        if (active) st4(P.out + (size_t)row * P.ld_out + c4, scale4(acc, di));
+        return;
+    }
     if (MODE == AGG_GAT_BWD_D) {
         const RowD r = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
         float dsum = 0.f;
@@ -213,26 +236,27 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
         if (it.slot < 0 && sub == 0 && active && c4 % P.F == 0) P.ksum[(size_t)row * P.ld_k + k] = 0.f;
         return;  // hub chunks of such a row leave their partial records alone: the merge kernel does not read them
     }
+    constexpr bool kSrc = MODE == AGG_GAT_BWD_S || MODE == AGG_SUM_BWD_S;   // walks a source row's out-edges, filtered
     RowD rd;
     RowS rs;
     if (MODE == AGG_GAT_BWD_D) rd = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
-    else rs = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
+    else if (MODE == AGG_GAT_BWD_S) rs = load_row_s<F4T>(P, row, c4, lane, pos, F4, pow2);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
     int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
-    if (MODE == AGG_GAT_BWD_S && P.row_active && src >= 0 && !row_live(P, src)) src = -1;
+    if (kSrc && P.row_active && src >= 0 && !row_live(P, src)) src = -1;
     // Batch-sparse S pass (the last layer: 2.5 % of the gathered rows carry a gradient): the surviving edges of SEVERAL batches
     // of 64 are queued (edge order kept) and processed together.  Packing each batch on its own (round 2) still paid one
     // whole 4-edges-per-subgroup iteration for the 1-2 survivors of nearly every batch: 0.32 ms to find and process the
     // 0.6 M live edges among 24.8 M.
     __shared__ int live_q[kBlock / kWave][kWave];
     const int wq = (int)threadIdx.x / kWave;
-    const bool queued = MODE == AGG_GAT_BWD_S && P.row_active != nullptr;
+    const bool queued = kSrc && P.row_active != nullptr;
     int q_n = 0;
     for (int base = it.beg; base < it.end; base += kWave) {
         const int nxt = base + kWave + lane;
         int src_next = nxt < it.end ? P.col[nxt] : -1;
-        if (MODE == AGG_GAT_BWD_S && P.row_active && src_next >= 0 && !row_live(P, src_next)) src_next = -1;
+        if (kSrc && P.row_active && src_next >= 0 && !row_live(P, src_next)) src_next = -1;
         int cnt = min(kWave, it.end - base);
         if (queued) {
             const unsigned long long live = __ballot(src >= 0);
@@ -276,6 +300,12 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
                 ok[u] = idx < cnt && j >= 0;
                 jj[u] = ok[u] ? j : 0;
             }
+            if (MODE == AGG_SUM_BWD_S) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ok[u]) acc = fma4(P.dinv[jj[u]], ld4(row_at(P.feat + c4, jj[u], P.ld_feat)), acc);
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 h[u] = ld4(row_at(P.feat + c4, jj[u], P.ld_feat));
@@ -301,14 +331,20 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
 #pragma unroll
     for (int off = G; off < kWave; off <<= 1) {
         dsum += __shfl_xor(dsum, off);
-        if (MODE == AGG_GAT_BWD_S) acc = add4(acc, shfl_xor4(acc, off));
+        if (kSrc) acc = add4(acc, shfl_xor4(acc, off));
     }
     if (it.slot >= 0) {  // hub chunk: partial record [acc (W) | per head: unused, dsum]
         if (sub == 0 && active) {
             float *rec = P.partial + (size_t)it.slot * (size_t)(P.W + 2 * nk);
-            if (MODE == AGG_GAT_BWD_S) st4(rec + c4, acc);
-            if (c4 % P.F == 0) rec[P.W + 2 * k + 1] = dsum;
+            if (kSrc) st4(rec + c4, acc);
+            if (MODE != AGG_SUM_BWD_S && c4 % P.F == 0) rec[P.W + 2 * k + 1] = dsum;
         }
+        return;
+    }
+    if (MODE == AGG_SUM_BWD_S) {
+        const float di = P.dinv_self[row];
+        if (P.self_loop && row_on) acc = fma4(di, ld4(row_at(P.feat_self + c4, row, P.ld_self)), acc);
+        if (sub == 0 && active) st4(P.out + (size_t)row * P.ld_out + c4, scale4(acc, di));
         return;
     }
     if (P.self_loop) {
@@ -377,15 +413,21 @@ __global__ __launch_bounds__(kBlock) void bwd_merge_kernel(const AggLaunch L) {
         for (int u = 0; u < UM; ++u) {
             const int c = c0 + u < count ? c0 + u : count - 1;
             const float *rec = P.partial + (size_t)(first + c) * rec_sz;
-            a[u] = MODE == AGG_GAT_BWD_S ? ld4(rec + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            dd[u] = rec[P.W + 2 * k + 1];
+            a[u] = MODE != AGG_GAT_BWD_D ? ld4(rec + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dd[u] = MODE != AGG_SUM_BWD_S ? rec[P.W + 2 * k + 1] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < UM; ++u) {
             const float f = c0 + u < count ? 1.f : 0.f;
-            if (MODE == AGG_GAT_BWD_S) acc = fma4(f, a[u], acc);
+            if (MODE != AGG_GAT_BWD_D) acc = fma4(f, a[u], acc);
             dsum = fmaf(f, dd[u], dsum);
         }
+    }
+    if (MODE == AGG_SUM_BWD_S) {
+        const float di = P.dinv_self[row];
+        if (P.self_loop && row_on) acc = fma4(di, ld4(row_at(P.feat_self + c4, row, P.ld_self)), acc);
+        if (sub == 0 && active) st4(P.out + (size_t)row * P.ld_out + c4, scale4(acc, di));
+        return;
     }
     if (MODE == AGG_GAT_BWD_D) {
         const RowD r = load_row_d<F4T>(P, row, c4, lane, pos, F4, pow2);
@@ -414,8 +456,9 @@ int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
     // names as profiles/summarize.py derives them from rocprofv3's kernel names (bwd_rows_kernel<G, MODE, F4T>)
     static char names[2][32];
     if (!names[0][0]) {
-        snprintf(names[0], sizeof(names[0]), "gat_bwd_%s_g%d", MODE == AGG_GAT_BWD_D ? "dst" : "src", G);
-        snprintf(names[1], sizeof(names[1]), "gat_bwd_%s_g%d_batch", MODE == AGG_GAT_BWD_D ? "dst" : "src", G);
+        const char *fam = MODE == AGG_SUM_BWD_S ? "sum_bwd" : "gat_bwd";
+        snprintf(names[0], sizeof(names[0]), "%s_%s_g%d", fam, MODE == AGG_GAT_BWD_D ? "dst" : "src", G);
+        snprintf(names[1], sizeof(names[1]), "%s_%s_g%d_batch", fam, MODE == AGG_GAT_BWD_D ? "dst" : "src", G);
     }
     const char *nm = names[sparse ? 1 : 0];
     AggLaunch L;
@@ -460,7 +503,8 @@ int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         }
         L.blk_start[L.n_groups] = blocks;
         if (blocks > 0) {
-            ProfScope ps(MODE == AGG_GAT_BWD_D ? "gat_bwd_dst_merge" : "gat_bwd_src_merge", stream, 0.0);
+            ProfScope ps(MODE == AGG_GAT_BWD_D ? "gat_bwd_dst_merge" : MODE == AGG_SUM_BWD_S ? "sum_bwd_src_merge" : "gat_bwd_src_merge",
+                         stream, 0.0);
             PEA_LAUNCH((bwd_merge_kernel<G, MODE, F4T>), dim3(blocks), dim3(kBlock), 0, stream, L);
             PEA_HIP(hipGetLastError());
         }
@@ -636,6 +680,7 @@ int launch_gat_backward(AggMode mode, const AggGroup *groups, int n_groups, hipS
     AggLaunch base;
     base.n_groups = n_groups;
     for (int i = 0; i < n_groups; ++i) base.g[i] = groups[i];
+    if (mode == AGG_SUM_BWD_S) return launch_bwd_mode<AGG_SUM_BWD_S>(base, stream);
     return mode == AGG_GAT_BWD_D ? launch_bwd_mode<AGG_GAT_BWD_D>(base, stream) : launch_bwd_mode<AGG_GAT_BWD_S>(base, stream);
 }
 

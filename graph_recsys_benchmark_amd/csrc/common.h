@@ -166,7 +166,10 @@ constexpr double kHotMinFraction = 0.15;    // ... nor those whose top-K sources
 // AGG_GAT_BWD_D / _S: the two gather passes of the GAT backward (agg.hip): D walks a destination row's in-edges
 // (gathers T_j) and yields d a_dst; S walks a source row's out-edges over the REVERSED relation (gathers the output
 // gradient rows g_i) and yields dT_j and d a_src.
-enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2, AGG_GAT_BWD_D = 3, AGG_GAT_BWD_S = 4, AGG_WSUM = 5 };
+// AGG_SUM_BWD_S: out_j = dinv_self_j (sum_i dinv_i feat_i + [self_loop] dinv_self_j feat_self_j) like AGG_GCN, on the
+//   backward kernels' batch-sparse walk (row_active: only flagged rows i are fetched; the surviving edges of several
+//   64-edge batches are queued): the last layer's reverse aggregation of GCN / SAGE, whose dX is the batch's rows only
+enum AggMode { AGG_GAT = 0, AGG_GCN = 1, AGG_MEAN = 2, AGG_GAT_BWD_D = 3, AGG_GAT_BWD_S = 4, AGG_WSUM = 5, AGG_SUM_BWD_S = 6 };
 
 // One horizontal group: C channel-heads of width F that share a relation, columns contiguous.
 struct AggGroup {

@@ -169,6 +169,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
                 a.ld_self = m->ld_x;
                 a.dinv = R.invdeg;           // 1 / max(deg_i, 1) of the gathered (forward destination) node
                 a.dinv_self = plan->ones;
+                a.row_active = m->active_rows;
                 a.row_active_bits = active_bits;
                 a.out = dT + g.col;
                 a.ld_out = L.ld_t;
@@ -218,8 +219,13 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
                 gs.push_back(a);
             }
         }
-        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups)
-            PEA_TRY(launch_aggregate(AGG_GCN, gs.data() + b, (int)std::min<size_t>(kMaxAggGroups, gs.size() - b), stream));
+        // level 1 with the batch's row flags: the batch-sparse walk of the backward kernels (only flagged rows are fetched)
+        const bool batch_walk = level == 1 && m->active_rows != nullptr;
+        for (size_t b = 0; b < gs.size(); b += kMaxAggGroups) {
+            const int nb = (int)std::min<size_t>(kMaxAggGroups, gs.size() - b);
+            if (batch_walk) PEA_TRY(launch_gat_backward(AGG_SUM_BWD_S, gs.data() + b, nb, stream));
+            else PEA_TRY(launch_aggregate(AGG_GCN, gs.data() + b, nb, stream));
+        }
         return PEA_OK;
     }
     if (d.kind == PEA_KIND_SAGE) {
@@ -404,7 +410,7 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             active_bits = m->active_bits;
         }
     }
-    std::vector<AggGroup> gd, gsrc;
+    std::vector<AggGroup> gd, gsrc, gsrc_batch;
     for (const GroupPlan &g : L.groups) {
         const int rr = m->reverse_of[(size_t)g.rel];
         PEA_REQUIRE(rr >= 0, PEA_ERR_ARG, "backward: relation %d has no reversed relation in the plan", g.rel);
@@ -432,8 +438,13 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             a.dinv_self = a.dinv;
             a.out = dT + g.col;
             a.ld_out = L.ld_t;
-            a.row_active_bits = g.last ? active_bits : nullptr;   // only the batch's rows of dX are non-zero
-            if (part_b) gsrc.push_back(a);
+            if (g.last && active_bits) {   // only the batch's rows of dX are non-zero: the batch-sparse walk (agg_bwd.hip)
+                a.row_active = m->active_rows;
+                a.row_active_bits = active_bits;
+                if (part_b) gsrc_batch.push_back(a);
+            } else if (part_b) {
+                gsrc.push_back(a);
+            }
             continue;
         }
         a.att_src = pack + L.att_src_off + g.col;
@@ -498,6 +509,8 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
         if (d.kind == PEA_KIND_GCN) PEA_TRY(launch_aggregate(AGG_GCN, gsrc.data() + b, nb, stream));
         else PEA_TRY(launch_gat_backward(AGG_GAT_BWD_S, gsrc.data() + b, nb, stream));
     }
+    for (size_t b = 0; b < gsrc_batch.size(); b += kMaxAggGroups)   // GCN, last layer
+        PEA_TRY(launch_gat_backward(AGG_SUM_BWD_S, gsrc_batch.data() + b, (int)std::min<size_t>(kMaxAggGroups, gsrc_batch.size() - b), stream));
     // Gradient reductions, one launch per run of groups whose columns (and heads) are contiguous:
     //   d bias[c] = sum_n g[n, c];   d att_j[c] = sum_n d a_src[n, head(c)] T[n, c];   d att_i likewise with d a_dst
     size_t gi = 0;

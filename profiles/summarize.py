@@ -18,9 +18,10 @@ def short(name):
         mode = {'0': 'gat', '1': 'gcn', '2': 'mean'}[m.group(3)]
         return '%s_g%s_%s' % (m.group(1).replace('_kernel', ''), m.group(2), mode)
     m = re.search(r'bwd_(rows|merge)_kernel<(\d+), *(\d+)', name)
-    if m:                        # backward gather passes: MODE 3 = D (destination rows), 4 = S (source rows); bench.py names
-        side = 'dst' if m.group(3) == '3' else 'src'
-        return 'gat_bwd_%s_g%s' % (side, m.group(2)) if m.group(1) == 'rows' else 'gat_bwd_%s_merge' % side
+    if m:                        # backward gather passes: MODE 3 = D (destination rows), 4 = S (source rows), 6 = the
+        side = 'dst' if m.group(3) == '3' else 'src'          # weighted reverse sum of GCN / SAGE; bench.py names
+        fam = 'sum_bwd' if m.group(3) == '6' else 'gat_bwd'
+        return '%s_%s_g%s' % (fam, side, m.group(2)) if m.group(1) == 'rows' else '%s_%s_merge' % (fam, side)
     m = re.search(r'mlp2_kernel<\d+, *\d+, *(true|false|0|1)>', name)
     if m:                        # the training instance also stores the hidden tile: its own line
         return 'mlp2_kernel_train' if m.group(1) in ('true', '1') else 'mlp2_kernel'
