@@ -63,3 +63,79 @@ def test_dense_half_rejects_bad_arguments():
     with pytest.raises(_lib.PeaError):                             # k = 6 is not a multiple of 4: refused by the library
         dense_batch([(torch.randn(64, 6, device='cuda'), torch.randn(6, 8, device='cuda'), torch.empty(64, 8, device='cuda'))])
     assert grad_weight([]) == []
+
+
+@pytest.mark.parametrize('emb,hid,out', [(64, 64, 16), (128, 128, 16), (64, 64, 8)])
+@pytest.mark.parametrize('form', ['gat', 'gcn', 'sage'])
+def test_fused_dense_backward_matches_float64(form, emb, hid, out):
+    """csrc/mlp2_bwd.hip on its own: dZ = (dT_1 W_1 [+ dR_1 W_1root]) gated by H > 0, dA = dZ W_0 [, dXr = dZ W_0root] for three
+    channels laid out side by side like the training workspace, all rows and a listed subset (rows outside the list untouched)."""
+    from graph_recsys_benchmark_amd.engine import RowSet, mlp2_backward_data, mlp2_backward_data_sage
+    g = torch.Generator(device='cuda').manual_seed(emb + out)
+    n, p = 3001, 3
+    dt1 = torch.randn(n, p * out + 4, generator=g, device='cuda')
+    dr1 = torch.randn(n, p * out, generator=g, device='cuda')
+    h = torch.randn(n, p * hid, generator=g, device='cuda')          # about half of the gates closed
+    w0 = [torch.randn(hid, emb, generator=g, device='cuda') * 0.1 for _ in range(p)]
+    w0r = [torch.randn(hid, emb, generator=g, device='cuda') * 0.1 for _ in range(p)]
+    w1 = [torch.randn(out, hid, generator=g, device='cuda') * 0.1 for _ in range(p)]
+    w1r = [torch.randn(out, hid, generator=g, device='cuda') * 0.1 for _ in range(p)]
+    mark = torch.zeros(n, 4, device='cuda')
+    mark[torch.randperm(n, generator=torch.Generator().manual_seed(1))[:700].cuda(), 2] = 1.0
+    live = RowSet(n, torch.device('cuda')).fill_from(mark, 4)
+    for rows in (None, live):
+        dz = torch.full((n, p * hid), float('nan'), device='cuda')
+        da = torch.full((n, p * emb), float('nan'), device='cuda')
+        dx = torch.full((n, p * emb), float('nan'), device='cuda')
+        if form == 'sage':
+            chans = [(w0[c], w0r[c], w1[c], w1r[c], c * out, c * out, c * hid, c * hid, c * emb, c * emb) for c in range(p)]
+            mlp2_backward_data_sage(chans, emb, hid, out, dt1, dr1, h, dz, da, dx, rows=rows)
+        else:
+            gcn = form == 'gcn'          # GCNConv.weight is [in, out]
+            chans = [((w0[c].t().contiguous() if gcn else w0[c]), (w1[c].t().contiguous() if gcn else w1[c]),
+                      c * out, c * hid, c * hid, c * emb) for c in range(p)]
+            mlp2_backward_data(chans, emb, hid, out, dt1, h, dz, da, rows=rows, weights_in_out=gcn)
+        sel = torch.arange(n, device='cuda') if rows is None else torch.nonzero(mark[:, 2]).flatten()
+        rest = torch.ones(n, dtype=torch.bool, device='cuda')
+        rest[sel] = False
+        for c in range(p):
+            d = dt1[sel, c * out:(c + 1) * out].double() @ w1[c].double()
+            if form == 'sage':
+                d = d + dr1[sel, c * out:(c + 1) * out].double() @ w1r[c].double()
+            z = d * (h[sel, c * hid:(c + 1) * hid] > 0).double()
+            _close(dz[sel, c * hid:(c + 1) * hid], z)
+            _close(da[sel, c * emb:(c + 1) * emb], z @ w0[c].double())
+            if form == 'sage':
+                _close(dx[sel, c * emb:(c + 1) * emb], z @ w0r[c].double())
+        assert torch.isnan(dz[rest]).all() and torch.isnan(da[rest]).all()      # listed rows only
+
+
+def test_row_sets_and_masked_weight_gradient():
+    """csrc/rows.hip + pea_gw_job's alternative operand: the rows of a table that hold a non-zero (or are flagged), in ascending
+    order with a device-side count; zeroing them again; a weight gradient over the list whose flagged rows read `scale * alt`."""
+    from graph_recsys_benchmark_amd.engine import RowSet, grad_weight
+    g = torch.Generator(device='cuda').manual_seed(9)
+    n = 5003
+    table = torch.zeros(n, 24, device='cuda')
+    hot = torch.tensor([0, 7, 64, 4095, 5002], device='cuda')
+    table[hot, torch.tensor([0, 23, 5, 11, 19], device='cuda')] = torch.tensor([1.0, -2.0, 1e-30, 3.0, -0.0], device='cuda')
+    also = torch.zeros(n, dtype=torch.uint8, device='cuda')
+    also[torch.tensor([7, 100], device='cuda')] = 1
+    rs = RowSet(n, torch.device('cuda')).fill_from(table, 24, also=also)
+    want = [0, 7, 64, 100, 4095]                       # -0.0 is a zero; row 100 comes from the flags
+    assert int(rs.count.item()) == len(want) and rs.ids[:len(want)].tolist() == want
+    assert rs.flags.nonzero().flatten().tolist() == want
+    filled = torch.ones(n, 24, device='cuda')
+    rs.zero_rows_of(filled, 16)
+    assert float(filled[want, :16].abs().sum()) == 0.0 and float(filled.sum()) == n * 24 - len(want) * 16
+    a = torch.randn(n, 64, generator=g, device='cuda')
+    b = torch.randn(n, 64, generator=g, device='cuda')
+    alt = torch.randn(n, 64, generator=g, device='cuda')
+    scale = torch.rand(n, generator=g, device='cuda')
+    mask = torch.zeros(n, dtype=torch.uint8, device='cuda')
+    mask[torch.tensor([7, 4095, 33], device='cuda')] = 1
+    got = grad_weight([(a, b, mask, alt, scale), (a[:, :16], b)], rows=rs)
+    idx = torch.tensor(want, device='cuda')
+    bb = torch.where(mask[idx].bool().unsqueeze(1), alt[idx].double() * scale[idx].double().unsqueeze(1), b[idx].double())
+    _close(got[0], a[idx].double().t() @ bb)
+    _close(got[1], a[idx, :16].double().t() @ b[idx].double())
