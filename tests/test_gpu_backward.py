@@ -189,11 +189,13 @@ def test_two_step_training_schedule_matches_float64_and_the_levelwise_schedule(k
             assert err <= 2e-4 * np.abs(w).max() + 1e-6 * g_max, 'schedule %s, %s: max err %.3e vs scale %.3e' % (mode, name, err, np.abs(w).max())
 
 
-def test_sparse_backward_equals_the_dense_one_over_several_steps(monkeypatch):
-    """The training backward walks the gradient's support (rows with a non-zero dT_1, compacted on the device: csrc/rows.hip) and
-    keeps dA_0 zero outside it from step to step.  Three steps with DIFFERENT batches on one model (so rows enter and leave
-    the support) against the same steps with PEA_SPARSE_BWD=0: the skipped rows contribute exact zeros, so every gradient
-    agrees to fp32 summation order (1e-5 of the tensor's scale)."""
+@pytest.mark.parametrize('kind', ['gat', 'gcn', 'sage'])
+def test_sparse_backward_equals_the_dense_one_over_several_steps(kind, monkeypatch):
+    """The training backward walks the gradient's support (rows with a non-zero dT_1 -- SAGE: or in the batch --, compacted on
+    the device: csrc/rows.hip) and keeps dA_0 (SAGE: dM_0 and the root blocks) zero outside it from step to step.  Three steps
+    with DIFFERENT batches on one model (so rows enter and leave the support) against the same steps with PEA_SPARSE_BWD=0:
+    the skipped rows contribute exact zeros, so every gradient agrees to fp32 summation order (1e-5 of the tensor's scale;
+    gradients that vanish analytically: of the largest gradient)."""
     n, blocks, rel = random_hin(53, n_user=1600, n_item=420, n_attr=30, e_u2i=12000, e_attr=900)
     u2i, a2i = rel['u2i'], rel['a2i']
     flip = lambda e: np.ascontiguousarray(e[::-1])
@@ -204,7 +206,7 @@ def test_sparse_backward_equals_the_dense_one_over_several_steps(monkeypatch):
     out = {}
     for mode in ('1', '0'):
         monkeypatch.setenv('PEA_SPARSE_BWD', mode)
-        model = build_model('gat', n, edges, [2, 2, 2], 64, 64, 16)
+        model = build_model(kind, n, edges, [2, 2, 2], 64, 64, 16)
         model.load_state_dict(random_state_dict(model, 21, scale=0.2))
         model.train()
         steps = []
@@ -220,6 +222,7 @@ def test_sparse_backward_equals_the_dense_one_over_several_steps(monkeypatch):
             assert 0 < int(live.count.item()) < n           # the support is a proper subset of the nodes here
     for (l1, g1), (l0, g0) in zip(out['1'], out['0']):
         assert l1 == l0
+        g_max = max(float(v.abs().max()) for v in g0.values())
         for k in g0:
             scale = float(g0[k].abs().max())
-            assert float((g1[k] - g0[k]).abs().max()) <= 1e-5 * scale + 1e-12, k
+            assert float((g1[k] - g0[k]).abs().max()) <= 1e-5 * scale + 1e-7 * g_max + 1e-12, k
