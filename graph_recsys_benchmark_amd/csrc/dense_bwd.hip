@@ -211,6 +211,108 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
         for (int v = 0; v < 4; ++v) dst[((wave * 4 + nt) * 4 + v) * 64 + lane] = acc[nt][v];
 }
 
+// stage 1 for full 128 x 128 blocks (width-128 models: Yelp presets; every [128, N] x [N, 128] job is four 64 x 64 blocks,
+// i.e. both operands read twice): the same pipeline on 32-row chunks of 128 + 128 columns; wave w owns tile rows 2w, 2w + 1
+// (sixteen 16 x 16 tiles).  70 KB of LDS per workgroup (dynamic), two workgroups per CU.  Measured SLOWER than four 64 x 64
+// blocks (see grad_weight_impl): kept for the record, off by default.
+constexpr int kGwLd128 = 136;
+extern __shared__ float gw_lds128[];
+__global__ __launch_bounds__(256) void gw_stage1_lds128(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
+    const int64_t n_rows = M.size();
+    float (*As)[32][kGwLd128] = reinterpret_cast<float (*)[32][kGwLd128]>(gw_lds128);
+    float (*Bs)[32][kGwLd128] = reinterpret_cast<float (*)[32][kGwLd128]>(gw_lds128 + 2 * 32 * kGwLd128);
+    const int job = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+    const GwJob &J = Jb.j[job];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int64_t chunk = ((n_rows + parts - 1) / parts + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)part * chunk, r1 = min(n_rows, r0 + chunk);
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // loader role: thread t moves float4 column (t % 32) of rows (t / 32) + 8 u, u = 0 .. 3, of a chunk, both operands
+    const int lr = tid >> 5, lc = (tid & 31) * 4;
+    float4 pa[2][4], pb[2][4];
+    unsigned char fl[4] = {0, 0, 0, 0};
+    int64_t rid[4] = {-1, -1, -1, -1};
+    auto flags = [&](int64_t base) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t n = base + lr + 8 * u;
+            const int64_t nr = n < r1 ? M.row(n) : -1;
+            const bool ok = nr >= 0 && nr < M.N;
+            rid[u] = ok ? nr : -1;
+            fl[u] = (J.b_mask && ok) ? J.b_mask[nr] : (unsigned char)0;
+        }
+    };
+    auto fetch = [&](auto SET) {
+        constexpr int set = decltype(SET)::value;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = rid[u] >= 0;
+            const int64_t nc = ok ? rid[u] : 0;
+            const float4 va = *reinterpret_cast<const float4 *>(J.a + nc * J.lda + lc);
+            float4 vb = *reinterpret_cast<const float4 *>((fl[u] ? J.b_alt + nc * J.ldb_alt : J.b + nc * J.ldb) + lc);
+            if (fl[u] && J.b_alt_scale) {
+                const float bs = J.b_alt_scale[nc];
+                vb = make_float4(bs * vb.x, bs * vb.y, bs * vb.z, bs * vb.w);
+            }
+            pa[set][u] = ok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[set][u] = ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](auto SET) {           // register set s -> LDS image s
+        constexpr int set = decltype(SET)::value;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *reinterpret_cast<float4 *>(&As[set][lr + 8 * u][lc]) = pa[set][u];
+            *reinterpret_cast<float4 *>(&Bs[set][lr + 8 * u][lc]) = pb[set][u];
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (r0 < r1) {
+        flags(r0);
+        fetch(I0());
+        flags(r0 + 32);
+        stash(I0());
+        fetch(I1());
+        flags(r0 + 64);
+    }
+    auto step = [&](auto CUR, auto NXT, int64_t base) {
+        constexpr int cur = decltype(CUR)::value;
+        __syncthreads();
+        const bool more1 = base + 32 < r1, more2 = base + 64 < r1;
+        if (more2) {
+            fetch(CUR);
+            flags(base + 96);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float a0 = As[cur][4 * s + kq][32 * wave + i], a1 = As[cur][4 * s + kq][32 * wave + 16 + i];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const float bv = Bs[cur][4 * s + kq][16 * nt + i];
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nt], 0, 0, 0);
+            }
+        }
+        if (more1) stash(NXT);
+    };
+    for (int64_t base = r0; base < r1; base += 64) {
+        step(I0(), I1(), base);
+        if (base + 32 < r1) step(I1(), I0(), base + 32);
+    }
+    float *dst = partial + ((size_t)job * parts + part) * (64 * 256);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dst[(((2 * wave + m) * 8 + nt) * 4 + v) * 64 + lane] = acc[m][nt][v];
+}
+
 // stage 2: out = sum over parts, part order.  Element e of a record: tile (mt, nt), register v, lane l ->
 // row 16 mt + 4 (l / 16) + v, column 16 nt + l % 16.
 template <int MT, int NT>
@@ -285,6 +387,27 @@ int launch_gw(const GwBatch &Jb, const RowMap &rows, float *partial, double byte
 
 int tiles_of(int w) { return w <= 16 ? 1 : w <= 32 ? 2 : 4; }
 
+int launch_gw128(const GwBatch &Jb, const RowMap &rows, float *partial, double bytes, int64_t n_rows, hipStream_t stream) {
+    constexpr size_t lds = (size_t)4 * 32 * kGwLd128 * sizeof(float);
+    static bool lds_set = false;
+    if (!lds_set) {
+        PEA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gw_stage1_lds128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = true;
+    }
+    // a record is 64 tiles (four of the 64 x 64 kind); two workgroups per CU
+    int parts = gw_parts(2 * Jb.n, n_rows, true);
+    parts = std::max(1, std::min(parts, kGwRecords / (4 * Jb.n)));
+    {
+        ProfScope ps("grad_weight", stream, bytes);
+        PEA_LAUNCH(gw_stage1_lds128, dim3((unsigned)Jb.n, (unsigned)parts), dim3(256), lds, stream, Jb, rows, partial);
+        PEA_HIP(hipGetLastError());
+    }
+    ProfScope ps("grad_weight_sum", stream);
+    PEA_LAUNCH((gw_stage2<8, 8>), dim3(64 * 4, (unsigned)Jb.n), dim3(256), 0, stream, Jb, partial, parts);
+    PEA_HIP(hipGetLastError());
+    return PEA_OK;
+}
+
 }  // namespace
 }  // namespace pea
 
@@ -329,12 +452,41 @@ static int grad_weight_impl(const pea::RowMap &rowmap, int64_t n_rows, int n_job
     PEA_REQUIRE(workspace && workspace_bytes >= pea_grad_weight_workspace_bytes(), PEA_ERR_NOMEM, "grad_weight: workspace too small");
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
     // cut every job into <= 64 x 64 blocks, group the blocks by tile shape, one pair of launches per shape and batch
-    std::vector<GwJob> blocks[3][3];
+    std::vector<GwJob> blocks[3][3], blocks128;
+    // OFF unless PEA_GW128=1: measured slower on the Yelp-shaped presets (0.84 vs 0.73 ms per step for SAGE, 0.50 vs 0.44 GAT,
+    // 0.48 vs 0.42 GCN: profiles/r03/gw128_r03.txt) although both operands are read once instead of twice -- the reduction is
+    // bound by its LDS -> MFMA dependency chain per workgroup, and the 70 KB image leaves 8 waves per CU where the 64 x 64
+    // kernel keeps 16
+    const char *env128 = getenv("PEA_GW128");
+    const bool use128 = env128 && atoi(env128) == 1;
     for (int q = 0; q < n_jobs; ++q) {
         const pea_gw_job &S = jobs_host[q];
         PEA_REQUIRE(S.a && S.b && S.out && S.ma > 0 && S.nb > 0 && S.lda >= S.ma && S.ldb >= S.nb && S.ldo >= S.nb,
                     PEA_ERR_ARG, "grad_weight: job %d malformed", q);
         PEA_REQUIRE(!S.b_mask || (S.b_alt && S.ldb_alt >= S.nb), PEA_ERR_ARG, "grad_weight: job %d has a row mask but no alternative operand", q);
+        // whole 128 x 128 blocks with float4-addressable operands: one block each (both operands read once)
+        if (use128 && S.ma % 128 == 0 && S.nb % 128 == 0 && S.lda % 4 == 0 && S.ldb % 4 == 0 &&
+            (reinterpret_cast<uintptr_t>(S.a) | reinterpret_cast<uintptr_t>(S.b)) % 16 == 0 &&
+            (!S.b_mask || (S.ldb_alt % 4 == 0 && reinterpret_cast<uintptr_t>(S.b_alt) % 16 == 0))) {
+            for (int i0 = 0; i0 < S.ma; i0 += 128)
+                for (int j0 = 0; j0 < S.nb; j0 += 128) {
+                    GwJob B;
+                    B.a = S.a + i0;
+                    B.b = S.b + j0;
+                    B.b_mask = S.b_mask;
+                    B.b_alt = S.b_mask ? S.b_alt + j0 : nullptr;
+                    B.b_alt_scale = S.b_mask ? S.b_alt_scale : nullptr;
+                    B.ldb_alt = S.ldb_alt;
+                    B.lda = S.lda;
+                    B.ldb = S.ldb;
+                    B.ma = 128;
+                    B.nb = 128;
+                    B.out = S.out + (int64_t)i0 * S.ldo + j0;
+                    B.ldo = S.ldo;
+                    blocks128.push_back(B);
+                }
+            continue;
+        }
         for (int i0 = 0; i0 < S.ma; i0 += 64)
             for (int j0 = 0; j0 < S.nb; j0 += 64) {
                 GwJob B;
@@ -353,6 +505,12 @@ static int grad_weight_impl(const pea::RowMap &rowmap, int64_t n_rows, int n_job
                 const int mt = tiles_of(B.ma), nt = tiles_of(B.nb);
                 blocks[mt == 1 ? 0 : mt == 2 ? 1 : 2][nt == 1 ? 0 : nt == 2 ? 1 : 2].push_back(B);
             }
+    }
+    for (size_t base = 0; base < blocks128.size(); base += kGwMaxJobs) {
+        GwBatch Jb;
+        Jb.n = (int)std::min<size_t>(kGwMaxJobs, blocks128.size() - base);
+        for (int q = 0; q < Jb.n; ++q) Jb.j[q] = blocks128[base + q];
+        PEA_TRY(launch_gw128(Jb, rowmap, partial, 4.0 * (double)n_rows * 256.0 * Jb.n, n_rows, (hipStream_t)stream));
     }
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) {

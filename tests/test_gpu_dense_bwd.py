@@ -14,7 +14,8 @@ def _close(got, want64, rtol=2e-5):
 
 
 @pytest.mark.parametrize('n', [1, 37, 4099, 150001])
-def test_grad_weight_matches_float64(n):
+def test_grad_weight_matches_float64(n, monkeypatch):
+    monkeypatch.setenv('PEA_GW128', '1' if n % 2 else '0')       # the (off by default) 128 x 128 kernel on the odd sizes
     from graph_recsys_benchmark_amd.engine import grad_weight
     g = torch.Generator(device='cuda').manual_seed(n)
     big = torch.randn(n, 200, generator=g, device='cuda')
@@ -30,6 +31,17 @@ def test_grad_weight_matches_float64(n):
         _close(out, a.double().t() @ b.double())
     again = grad_weight(pairs)                        # fixed reduction order: bitwise reproducible
     assert all(torch.equal(x, y) for x, y in zip(outs, again))
+    # width-128 models: whole 128 x 128 blocks take their own kernel (csrc/dense_bwd.hip: gw_stage1_lds128), with and without the
+    # alternative operand; a 256 x 128 job is two of them
+    wide_a = torch.randn(n, 256, generator=g, device='cuda')
+    wide_b = torch.randn(n, 132, generator=g, device='cuda')
+    alt = torch.randn(n, 128, generator=g, device='cuda')
+    scale = torch.rand(n, generator=g, device='cuda')
+    mask = (torch.rand(n, generator=g, device='cuda') < 0.4).to(torch.uint8)
+    got = grad_weight([(wide_a[:, :128], wide_b[:, :128]), (wide_a, wide_b[:, :128], mask, alt, scale)])
+    _close(got[0], wide_a[:, :128].double().t() @ wide_b[:, :128].double())
+    bb = torch.where(mask.bool().unsqueeze(1), alt.double() * scale.double().unsqueeze(1), wide_b[:, :128].double())
+    _close(got[1], wide_a.double().t() @ bb)
 
 
 def test_dense_batch_matches_float64():
