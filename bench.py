@@ -590,6 +590,27 @@ def training_leg(dataset, model, batch, args, timed_region, train_steps, world, 
                 'what': 'zero_grad + full-graph forward + BPR loss + backward + Adam step (torch.optim.Adam, fused=True)'
                         + (' (row-sharded over %d ranks: gradient-row fill-ins, gradient all-reduce, dx all-gather)' % world
                            if world > 1 else '')})
+    eng = getattr(model, '_train_engine', None)
+    layout = getattr(getattr(eng, 'plan', None), 'layout', None) if eng is not None else None
+    if layout is not None and getattr(layout, 'dry', False):
+        # emulated rank: the collectives were skipped; what each would have moved was noted (ShardLayout.dry_log) -> the same
+        # xGMI model as the forward's exchange_model, nothing overlapped (the training step's exchanges are synchronous)
+        layout.dry_log.clear()
+        train_step()
+        torch.cuda.synchronize()
+        w = layout.world
+        bw = (w - 1) * XGMI_GBS_PER_DIRECTION * RCCL_EFFICIENCY * 1e9
+        gathers = [b for k, b in layout.dry_log if k == 'all_gather']
+        reduces = [b for k, b in layout.dry_log if k == 'all_reduce']
+        ms = sum(b / bw * 1e3 + COLLECTIVE_LATENCY_MS for b in gathers) + \
+            sum(2.0 * b * (w - 1) / w / bw * 1e3 + COLLECTIVE_LATENCY_MS for b in reduces)
+        res['exchange_model'] = {
+            'all_gathers': len(gathers), 'all_gather_bytes_received_per_rank': float(sum(gathers)),
+            'all_reduces': len(reduces), 'all_reduce_bytes': float(sum(reduces)), 'exchange_model_ms': ms,
+            'projected_ms_per_step': res['ms_per_step'] + ms,
+            'assumptions': 'NOT measured. xGMI %.1f GB/s per link and direction, %d peers, RCCL at %.0f %% of the link rate, %.0f us '
+                           'per collective, no overlap with compute' % (XGMI_GBS_PER_DIRECTION, w - 1, RCCL_EFFICIENCY * 100,
+                                                                       COLLECTIVE_LATENCY_MS * 1e3)}
     live = getattr(model._train_engine, '_live_rows', None) if getattr(model, '_train_engine', None) is not None else None
     if live is not None:     # rows the loss's gradient reaches beyond the last layer (csrc/rows.hip): the dense backward walks these
         res['gradient_support_rows'] = int(live.count.item())

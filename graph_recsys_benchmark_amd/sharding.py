@@ -99,6 +99,7 @@ class ShardLayout:
         self._gather_plan = {}
         self._flags = {}
         self.dry = False   # True: skip the collectives (single-process rehearsal of one rank's compute + host work)
+        self.dry_log = []  # ... and note what each would have moved: (kind, bytes this rank would receive / reduce)
 
     @classmethod
     def verify_inplace_all_gather(cls, device, group=None, rows=4096):
@@ -152,6 +153,8 @@ class ShardLayout:
         """buf: contiguous [world * block_rows, ld]; block `rank` holds this rank's rows, the others are filled in.
         async_op (RCCL only): the collective is issued on RCCL's own stream behind the work already enqueued on the
         current stream and a work handle is returned; kernels launched afterwards run beside it until wait_all()."""
+        if self.dry and self.world > 1 and block_rows:
+            self.dry_log.append(('all_gather', (self.world - 1) * block_rows * buf.stride(0) * buf.element_size()))
         if self.world == 1 or block_rows == 0 or self.dry:
             return None
         mine = buf[self.rank * block_rows:(self.rank + 1) * block_rows]
@@ -210,6 +213,8 @@ class ShardLayout:
     def reduce_rows(self, rows, group=None):
         """Sum over the ranks of rows [K, W] in which every rank filled the entries it owns and zeroed the others (x + 0 is
         exact): the second half of gather_rows for rows a kernel already selected."""
+        if self.dry and self.world > 1:
+            self.dry_log.append(('all_reduce', rows.numel() * rows.element_size()))
         if self.world == 1 or self.dry:
             return rows
         done = CommTimer.span(rows.device)
@@ -251,6 +256,7 @@ class ShardLayout:
             mine = self.owner(ids) == self.rank   # rows of other ranks are undefined here (may hold NaN): select, never scale
             rows = torch.where(mine.view(-1, *([1] * (rows.dim() - 1))), rows, torch.zeros((), dtype=rows.dtype, device=rows.device))
         if self.dry:
+            self.dry_log.append(('all_reduce', rows.numel() * rows.element_size()))
             return rows
         done = CommTimer.span(rows.device)
         if dist.get_backend(group) == 'nccl':
@@ -348,6 +354,8 @@ class ShardLayout:
         """Sum every tensor of the list over the ranks, in place, with ONE collective on a flat copy (the ranks' shares of
         the parameter gradients of a sharded training step)."""
         tensors = [t for t in tensors if t is not None and t.numel()]
+        if self.dry and self.world > 1 and tensors:
+            self.dry_log.append(('all_reduce', sum(t.numel() * t.element_size() for t in tensors)))
         if self.world == 1 or not tensors or self.dry:
             return
         flat = torch.cat([t.reshape(-1) for t in tensors])
