@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument('--preset', default='ml25m_shaped')
     ap.add_argument('--kind', default='gat', choices=['gat', 'gcn', 'sage'])
     ap.add_argument('--scale', type=float, default=1.0, help='edge/node count multiplier (tests only)')
+    ap.add_argument('--hbm-scale', type=float, default=1.0,
+                    help='scale of the stress_10m (BASELINE configs[4]) leg of the default run: 1.0 = the whole configuration')
     ap.add_argument('--metapaths', type=int, default=0, help='use the first n metapaths of the dataset table (0 = the preset\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=3, help='timed runs of the CPU oracle (median reported)')
@@ -533,7 +535,14 @@ def main():
         torch.cuda.empty_cache()
         out['metapaths_13'] = thirteen_metapaths(dataset, args, device, batch, timed_region, not args.no_cpu_baseline)
     if single and not args.no_extras and args.preset == 'ml25m_shaped' and not args.metapaths and args.scale == 1.0:
-        out['hbm_resident'] = hbm_resident_leg(args, device, timed_region, not args.no_cpu_baseline)
+        # BASELINE configs[4] at FULL size (10 M nodes, 200 M edges, 16 metapaths, emb 128: 240 of the 288 GB of HBM, ~100 s of
+        # the run, most of it generating the graph on the host); should the card not have that much free, at 30 %
+        try:
+            out['hbm_resident'] = hbm_resident_leg(args, device, timed_region, not args.no_cpu_baseline, scale=args.hbm_scale)
+        except torch.cuda.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            out['hbm_resident'] = hbm_resident_leg(args, device, timed_region, not args.no_cpu_baseline, scale=0.3)
+            out['hbm_resident']['fallback'] = 'scale %g did not fit the free HBM' % args.hbm_scale
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -740,12 +749,13 @@ def eval_variant(dataset, model, args, timed_region):
                                      'ranks_differing': int((want_rank != got_rank).sum())}}
 
 
-def hbm_resident_leg(args, device, timed_region, with_check, scale=0.3):
-    """The same step on a workload whose gather tables do NOT fit the 256 MiB Infinity Cache (BASELINE config 5 at 30 %:
-    3 M nodes, 60 M edges, 16 metapaths, emb / hidden 128; item table of the 9-channel layer-2 gather: 600 k x 576 B):
-    the default workload's tables (26-42 MB) are cache resident, this one shows the kernels against HBM.  Its PMC
-    profile is profiles/r02/summary_r02s.json (traffic.json key 'stress_10m@0.3/gat').  Parity: sampled destination rows
-    of two channels recomputed in float64 on their 2-hop in-neighbourhood (oracle/rows64.py)."""
+def hbm_resident_leg(args, device, timed_region, with_check, scale=1.0):
+    """The same step on a workload whose gather tables do NOT fit the 256 MiB Infinity Cache: BASELINE config 5 (stress_10m:
+    10 M nodes, 200 M edges, 16 metapaths, emb / hidden 128; item table of the 9-channel layer-2 gather: 2 M x 576 B) at
+    `scale` (1.0: the whole configuration on ONE GPU; 0.3 was the default until round 3).  The default workload's tables
+    (26-42 MB) are cache resident, this one shows the kernels against HBM.  PMC profiles: traffic.json keys 'stress_10m/gat'
+    (profiles/r03/summary_r03s.json) and 'stress_10m@0.3/gat' (profiles/r02/summary_r02s.json).  Parity: sampled destination
+    rows of two channels recomputed in float64 on their 2-hop in-neighbourhood (oracle/rows64.py)."""
     from graph_recsys_benchmark_amd import _lib
     from graph_recsys_benchmark_amd.utils import SyntheticHIN, metapath_table
     ds = SyntheticHIN('stress_10m', seed=2019, scale=scale)
@@ -757,9 +767,9 @@ def hbm_resident_leg(args, device, timed_region, with_check, scale=0.3):
         with torch.no_grad():
             return model.loss(batch)
 
-    for _ in range(3):
+    for _ in range(2):
         step()
-    steps = 8
+    steps = 8 if scale < 0.6 else 4
     dt, loss = timed_region(step, steps)
     timed_region(step, steps, True)
     prof = read_profile()
