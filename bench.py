@@ -539,7 +539,9 @@ def main():
         # the run, most of it generating the graph on the host); should the card not have that much free, at 30 %
         try:
             out['hbm_resident'] = hbm_resident_leg(args, device, timed_region, not args.no_cpu_baseline, scale=args.hbm_scale)
-        except torch.cuda.OutOfMemoryError:
+        except (torch.cuda.OutOfMemoryError, _lib.PeaError) as e:     # (the plan's CSR arrays come from hipMalloc: PeaError)
+            if not isinstance(e, torch.cuda.OutOfMemoryError) and 'memory' not in str(e).lower():
+                raise
             torch.cuda.empty_cache()
             out['hbm_resident'] = hbm_resident_leg(args, device, timed_region, not args.no_cpu_baseline, scale=0.3)
             out['hbm_resident']['fallback'] = 'scale %g did not fit the free HBM' % args.hbm_scale
