@@ -117,8 +117,12 @@ __global__ __launch_bounds__(256) void gw_stage1(const GwBatch Jb, const RowMap 
 // added in the same order as above within a part (the k index of the MFMA steps runs over the rows in order), so the
 // results agree with the dword version bit for bit per tile... up to which wave owned which rows there: that version
 // summed four interleaved row subsets and added them; this one adds all rows of the part in order.
-constexpr int kGwLd = 72;   // row stride of the LDS images: lanes (kq, i) of an operand read land two per bank (the minimum
-                            // for 64 lanes), and 36 KB per workgroup lets FOUR of them share a CU (80: 41 KB, three)
+// LDS images: 64 floats per row, no padding; row r is stored ROTATED by 16 (r & 3) floats, so the four rows a wave's operand
+// read touches (lanes (kq, i): row 4s + kq, column c0 + i) fall into four different 16-bank groups of the 64 banks.  A
+// padded stride of 72 floats (round 3's first version) put them 8 banks apart: SQ_LDS_BANK_CONFLICT = 42 % of the LDS-active
+// cycles (profiles/r03/sq_gw_r03.txt).  32 KB per workgroup.
+constexpr int kGwLd = 64;
+__device__ __forceinline__ int gw_swz(int r, int c) { return (c + 16 * (r & 3)) & 63; }
 __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const RowMap M, float *__restrict__ partial) {
     const int64_t n_rows = M.size();
     __shared__ float As[2][32][kGwLd], Bs[2][32][kGwLd];
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
     f32x4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (two accumulator sets -- even / odd k-steps, 8 independent MFMA chains per wave instead of 4 -- measured SLOWER: 0.107 ->
+    // 0.151 ms on the nine first-layer blocks; so did whole 128 x 128 blocks; bank conflicts, prefetch depth and residency were
+    // each ruled out by a measurement: profiles/r03/sq_gw_r03.txt, gw_bench_r03.txt)
     // loader role: thread t moves float4 column (t % 16) of rows (t / 16) and (t / 16) + 16 of a 32-row chunk, both operands.
     // Software pipeline, per chunk c: row ids + operand flags (c - 3 .. c - 2: one step ahead of the loads they steer -- a
     // flag or a listed row id read in the same step sat in front of every operand load: 0.56 -> 0.84 ms on the nine
@@ -169,8 +176,8 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
     auto stash = [&](int set, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<float4 *>(&As[buf][lr + 16 * u][lc]) = pa[set][u];
-            *reinterpret_cast<float4 *>(&Bs[buf][lr + 16 * u][lc]) = pb[set][u];
+            *reinterpret_cast<float4 *>(&As[buf][lr + 16 * u][gw_swz(lr + 16 * u, lc)]) = pa[set][u];
+            *reinterpret_cast<float4 *>(&Bs[buf][lr + 16 * u][gw_swz(lr + 16 * u, lc)]) = pb[set][u];
         }
     };
     if (r0 < r1) {
@@ -193,10 +200,10 @@ __global__ __launch_bounds__(256) void gw_stage1_lds(const GwBatch Jb, const Row
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const float av = As[cur][4 * s + kq][16 * wave + i];
+            const float av = As[cur][4 * s + kq][gw_swz(kq, 16 * wave + i)];     // (4 s + kq) & 3 == kq
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[cur][4 * s + kq][16 * nt + i], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[cur][4 * s + kq][gw_swz(kq, 16 * nt + i)], acc[nt], 0, 0, 0);
         }
         if (more1) stash(cur ^ 1, cur ^ 1);   // chunk it + 1, loaded while chunks it - 1 and it were multiplied
     };
