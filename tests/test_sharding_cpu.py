@@ -145,3 +145,31 @@ def test_single_rank_is_identity():
     assert s.owned_rows().tolist() == list(range(1000))
     t = torch.randn(1000, 4)
     assert s.allgather_rows(t) is t
+
+
+def test_dry_rank_notes_what_its_collectives_would_move():
+    """A rehearsed rank (ShardLayout.dry: bench.py --emulate-world) skips its collectives and notes each one's volume instead --
+    the input of bench.py's modelled exchange: an all-gather is logged with the bytes the rank would RECEIVE ((world - 1) blocks),
+    an all-reduce with the bytes of its operand; the rows it owns stay as it computed them (the other ranks' never arrive)."""
+    import torch
+    from graph_recsys_benchmark_amd.sharding import ShardLayout
+    n, world = 4096, 4
+    s = ShardLayout(n, 1, world, tile=64)
+    s.dry = True
+    table = torch.arange(n * 8, dtype=torch.float32).view(n, 8)
+    before = table.clone()
+    s.allgather_rows(table)                                        # rank-major staging buffer [world * m, 8]
+    m = max(int(s.rows_of(r).numel()) for r in range(world))
+    assert s.dry_log[-1] == ('all_gather', (world - 1) * m * 8 * 4)
+    rows = s.gather_rows(table, torch.tensor([0, 70, 4095]))       # rows of other ranks come back as zeros, nothing is summed
+    assert s.dry_log[-1] == ('all_reduce', 3 * 8 * 4)
+    own = s.owner(torch.tensor([0, 70, 4095])) == 1
+    assert torch.equal(rows[own], before[torch.tensor([0, 70, 4095])[own]]) and float(rows[~own].abs().sum()) == 0.0
+    s.all_reduce_sum_([torch.ones(5), None, torch.ones(3, 3)])
+    assert s.dry_log[-1] == ('all_reduce', (5 + 9) * 4)
+    lay = s.source_layout(torch.tensor([[3, 3, 900, 2000, 4000], [0, 1, 2, 3, 4]]))
+    buf = torch.zeros(world * lay.slots_per_rank, 8)
+    s.exchange_sources(buf, table, lay, 0, 8)
+    assert s.dry_log[-1] == ('all_gather', (world - 1) * lay.slots_per_rank * 8 * 4)
+    mine = s.rows_of(1)
+    assert len(s.dry_log) == 4 and torch.equal(table[mine], before[mine])
