@@ -294,7 +294,7 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             continue
         units = lv['units']
         if s == 0 and lay.two_step_train:
-            # Two-step training schedule (csrc/model.h: fused2_train; GAT, one head, single GPU).  dO_0 holds dZ_0, the
+            # Two-step training schedule (csrc/model.h: fused2_train; GAT with one head or GCN, single GPU; SAGE: above).  dO_0 holds dZ_0, the
             # gradient of the first transform's pre-activations (masked by the gated product above); A_0 (T_0 region) holds the
             # aggregates of the rows with incoming edges (the others' input is x itself).  Dense half on views: dW_0 = dZ_0^T A_0 and dA_0 = dZ_0 W_0 per channel;
             # then ONE call runs the softmax passes in x space (bias gradient, D pass, S pass -> per-channel dx parts over A_0).

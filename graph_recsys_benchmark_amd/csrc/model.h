@@ -67,14 +67,16 @@ struct pea_model {
     double compulsory_bytes = 0.0;        // HBM floor of one forward: every buffer of the schedule written once and read once
     bool single_conv = false;             // pea_*_conv: any output width, X goes to the caller's buffer
     bool backward = false;                // training buffers allocated
-    // SAGE without training buffers runs on the GAT/GCN schedule: transform first (mean_j(W x_j) = W mean_j(x_j)), so the
-    // layers gather output-width rows; the root term lin_root(x_i) + bias is written first and the mean is added to it
+    // SAGE without training buffers -- or training on the two-step schedule below -- runs on the GAT/GCN schedule: transform
+    // first (mean_j(W x_j) = W mean_j(x_j)), so the layers gather output-width rows; the root term lin_root(x_i) + bias is
+    // written first and the mean is added to it
     bool sage2 = false;
     // GAT / GCN models of 2-step channels (every reference configuration) without training buffers run the TWO-STEP
     // INFERENCE SCHEDULE: the first layer aggregates x itself (logits from x . (W^T att)), and ONE kernel applies both
     // layers' transforms to the aggregate (csrc/mlp2.hip): T_0 / O_0 are never materialised.  PEA_FUSED2=0: level-wise.
     bool fused2 = false;
-    // The same schedule for TRAINING (round 3; GAT, one head, emb == hidden 64 / 128, single GPU; PEA_FUSED2_TRAIN=0: level-wise):
+    // The same schedule for TRAINING (round 3; GAT with one head, GCN, SAGE; emb == hidden 64 / 128, single GPU;
+    // PEA_FUSED2_TRAIN=0: level-wise; GCN / SAGE: their linear aggregation's backward is the reverse aggregation, model_bwd.hip):
     // the first layer aggregates x (softmax statistics kept), the fused transform also stores the hidden tile H = O_0;
     // the backward then runs the first layer's softmax passes in x space
     // (gather sources: x rows and the rows of dA_0 = dZ_0 W_0) -- T_0 is never built, and the first layer's forward gathers
