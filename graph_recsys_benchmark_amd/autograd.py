@@ -213,9 +213,7 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
                           (dO[:, c:c + u['HF']], x)]
             mlp2_backward_data_sage(chans, emb, units[0]['HF'], u1_of[units[0]['p']]['HF'], dT1, dX, H, dO, dT, side, rows=live)
             dWs = grad_weight(pairs, rows=live)
-            # (PEA_BWD0_FILTER=1: gathered rows outside the list are not fetched -- measured slower, see the GCN branch below)
-            filt = live is not None and os.environ.get('PEA_BWD0_FILTER', '0') == '1'
-            _lib.check(lib.pea_model_set_active_rows0(engine._h, _lib.ptr(live.flags) if filt else None,
+            _lib.check(lib.pea_model_set_active_rows0(engine._h, None,
                                                       None if live is None else _lib.ptr(live.ids),
                                                       None if live is None else _lib.ptr(live.count)))
             level_call(0, 0)          # d bias0; per channel: dM_0 spread over the reversed relation + the root block -> over A_0
@@ -334,9 +332,8 @@ def backward_conv_stack(engine, d_stack, x, layer_params, active_ids=None, compa
             dWs = grad_weight(pairs, rows=live)
             # no flags: 3/4 of the rows these gathers fetch are live, and a test per edge costs more than the quarter of the
             # fetches it saves -- GAT S pass 1.12 -> 1.23 ms, GCN reverse aggregation 1.47 -> 1.75, SAGE 0.82 -> 1.09 on the
-            # 25m-shaped graph (PEA_BWD0_FILTER=1 turns the GCN / SAGE test on: profiles/r03/bwd0_filter_r03.txt)
-            filt = gcn and live is not None and os.environ.get('PEA_BWD0_FILTER', '0') == '1'
-            _lib.check(lib.pea_model_set_active_rows0(engine._h, _lib.ptr(live.flags) if filt else None,
+            # 25m-shaped graph (profiles/r03/bwd0_filter_r03.txt; the GCN / SAGE test lived in the forward kernels and was removed)
+            _lib.check(lib.pea_model_set_active_rows0(engine._h, None,
                                                       None if live is None else _lib.ptr(live.ids),
                                                       None if live is None else _lib.ptr(live.count)))
             level_call(0, 0)

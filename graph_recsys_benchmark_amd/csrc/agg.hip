@@ -84,7 +84,6 @@ __device__ __forceinline__ void short_rows(const AggGroup &P, const int blk) {
     if (MODE == AGG_GAT) {
         for (int off = G; off < kWave; off <<= 1) len = max(len, __shfl_xor(len, off));
     }
-    const unsigned *live_bits = MODE == AGG_GCN ? P.row_active_bits : nullptr;
     constexpr int U = 4;  // edges in flight per subgroup: U ids, then U gathered rows, then one softmax update for the U
     for (int t = 0; t < len; t += U) {
         int jj[U];
@@ -97,26 +96,11 @@ __device__ __forceinline__ void short_rows(const AggGroup &P, const int blk) {
             ok[u] = e < end;
             jj[u] = ok[u] ? P.col[e] : 0;
         }
-        if (MODE == AGG_GCN && live_bits) {   // gathered rows known to be zero are not fetched (see AggGroup::row_active_bits)
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (ok[u] && !((live_bits[(unsigned)jj[u] >> 5] >> ((unsigned)jj[u] & 31u)) & 1u)) ok[u] = false, jj[u] = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                a[u] = 0.f;
-                if (ok[u]) {
-                    h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
-                    a[u] = P.dinv[jj[u]];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
-                if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
-                if (MODE == AGG_WSUM) a[u] = ok[u] ? P.edge_w[P.eid[beg + t + u]] : 0.f;
-            }
+        for (int u = 0; u < U; ++u) {
+            h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
+            if (MODE == AGG_GCN) a[u] = P.dinv[jj[u]];
+            if (MODE == AGG_WSUM) a[u] = ok[u] ? P.edge_w[P.eid[beg + t + u]] : 0.f;
         }
         if (MODE == AGG_GAT) {
 #pragma unroll
@@ -190,7 +174,6 @@ __device__ __forceinline__ void long_item(const AggGroup &P, const LongItem it, 
     const int kk = 2 * (c4 / P.F);
     const int F4 = P.F / 4, pos = sl % F4;
     const bool pow2 = (F4 & (F4 - 1)) == 0;
-    const unsigned *live_bits = MODE == AGG_GCN ? P.row_active_bits : nullptr;
     float a_d = 0.f, di = 0.f;
     const float slope = P.neg_slope;  // kept in a register: read inside the edge loop it became a scalar load + wait per edge
     float4 att_s = make_float4(0.f, 0.f, 0.f, 0.f), h_self = att_s;
@@ -219,23 +202,8 @@ __device__ __forceinline__ void long_item(const AggGroup &P, const LongItem it, 
                 ok[u] = idx < cnt && j != -1;
                 jj[u] = ok[u] ? j : 0;
             }
-            if (MODE == AGG_GCN && !HOT && live_bits) {   // gathered rows known to be zero are not fetched
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (ok[u] && !((live_bits[(unsigned)jj[u] >> 5] >> ((unsigned)jj[u] & 31u)) & 1u)) ok[u] = false, jj[u] = 0;
-            }
-            const bool filtered = MODE == AGG_GCN && !HOT && live_bits != nullptr;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (filtered) {
-                    h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    a[u] = 0.f;
-                    if (ok[u]) {
-                        h[u] = ld4(row_at(feat, jj[u], P.ld_feat));
-                        a[u] = P.dinv[jj[u]];
-                    }
-                    continue;
-                }
                 if (HOT && jj[u] < 0) {  // image row (ds_read_b128), no memory traffic
                     const int r = -(jj[u] + 2);
                     h[u] = img[r * W4 + lc];

@@ -85,7 +85,6 @@ struct pea_model {
     // two-step training schedule, level 0: rows whose gradient dA_0 is not identically zero (flags [N], compacted ids and
     // their device-side count: csrc/rows.hip); null: every row
     const unsigned char *active0 = nullptr;
-    long active0_epoch = 0, active0_bits_of = -1;   // the bitmap in active_bits was built from the flags of this epoch
     const int *active0_list = nullptr, *active0_count = nullptr;
     const float *last_x = nullptr;        // x of the last training forward (the level-0 backward gathers its rows)
     int64_t last_ldx = 0;

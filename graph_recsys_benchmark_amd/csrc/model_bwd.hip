@@ -75,27 +75,10 @@ extern "C" int pea_model_set_active_rows0(pea_model *m, const unsigned char *fla
     PEA_REQUIRE((list == nullptr) == (count_dev == nullptr) && (flags == nullptr || list != nullptr), PEA_ERR_ARG,
                 "set_active_rows0: a list comes with its count, flags with the list");
     m->active0 = flags;              // NULL with a list: the gathers run over every row (dA_0 is zero outside the list)
-    ++m->active0_epoch;
     m->active0_list = list;
     m->active0_count = count_dev;
     return PEA_OK;
 }
-
-namespace {
-// bitmap of the level-0 row flags (pea_model_set_active_rows0), built once per backward call; NULL flags: no filter
-int active0_bits(pea_model *m, int64_t N, hipStream_t stream, const unsigned **out) {
-    *out = nullptr;
-    if (!m->active0) return PEA_OK;
-    if (!m->active_bits) PEA_HIP(hipMalloc((void **)&m->active_bits, (size_t)((N + 63) / 64) * 2 * sizeof(unsigned)));
-    if (m->active0_bits_of != m->active0_epoch) {
-        PEA_LAUNCH(flags_to_bits_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, m->active0, m->active_bits);
-        PEA_HIP(hipGetLastError());
-        m->active0_bits_of = m->active0_epoch;
-    }
-    *out = m->active_bits;
-    return PEA_OK;
-}
-}  // namespace
 
 extern "C" int pea_model_set_active_rows(pea_model *m, const unsigned char *row_active) {
     PEA_REQUIRE(m, PEA_ERR_ARG, "set_active_rows: null model");
@@ -184,8 +167,6 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
             const int E0 = d.emb_dim;
             const RowMap live = m->active0_list ? make_rowmap_list(N, m->active0_list, m->active0_count, N) : own;
             PEA_TRY(launch_colsum(live, L.n_cols, L.n_cols, dO, L.ld_o, nullptr, 0, 1.0f, colsum_part, gpack + L.bias_off, stream));
-            const unsigned *live_bits = nullptr;
-            PEA_TRY(active0_bits(m, N, stream, &live_bits));
             size_t part_off = 0;
             for (size_t ui = 0; ui < L.units.size(); ++ui) {
                 const Unit &u = L.units[ui];
@@ -197,7 +178,6 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
                             "backward: hub partial buffer too small for relation %d and its reverse", u.rel);
                 PEA_TRY(ensure_sage_arrays(plan, u.rel, stream));
                 AggGroup a{};
-                a.row_active_bits = live_bits;
                 fill_lists(a, Rr);
                 a.W = E0;
                 a.F = E0;
@@ -298,7 +278,6 @@ extern "C" int pea_model_backward_level(pea_model *m, int level, int phase, void
                 const bool fc = d.gcn_deg_from_col != 0;
                 PEA_TRY(ensure_dinv(plan, u.rel, fc, stream));
                 AggGroup a{};
-                PEA_TRY(active0_bits(m, N, stream, &a.row_active_bits));
                 fill_lists(a, Rr);
                 a.W = E0;
                 a.F = E0;
