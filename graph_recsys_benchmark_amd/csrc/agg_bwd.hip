@@ -109,7 +109,11 @@ __device__ __forceinline__ void finish_s(const AggGroup &P, const RowS &r, int r
 }
 
 // ------------------------------------------------------------------------------------------------ short rows
-template <int G, int MODE, int F4T>
+// SP (here and in bwd_long_item): the launch has groups with row flags (the last layer of a training step).  The dense
+// launches (SP = false: the first layer's x-space passes, 1.9 of the step's 5.6 ms) are compiled without the flag tests and
+// the survivor queue: as run-time branches on a null pointer they cost the S pass 127 M scalar instructions per launch
+// against 38 M of the D pass (SQ_INSTS_SALU, profiles/collect_sq_kind.sh gat train).
+template <int G, int MODE, int F4T, bool SP>
 __device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk) {
     const int item = blk * (kBlock / G) + (int)threadIdx.x / G;
     const int sl = (int)threadIdx.x % G, lane = (int)threadIdx.x % kWave;
@@ -119,7 +123,7 @@ __device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk)
     const int c4 = active ? sl * 4 : 0;
     // row_active (optional): rows whose output gradient is exactly zero (every row outside the BPR batch, for the last
     // layer) contribute nothing: the D pass writes d a_dst = 0 for them without gathering, the S pass skips their edges
-    const bool row_on = !P.row_active || P.row_active[row] != 0;
+    const bool row_on = !SP || !P.row_active || P.row_active[row] != 0;
     const int beg = P.rowptr[row];
     const int end = (valid && (MODE != AGG_GAT_BWD_D || row_on)) ? P.rowptr[row + 1] : beg;
     const int F4 = P.F / 4, pos = sl % F4;
@@ -138,7 +142,7 @@ __device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk)
             for (int u = 0; u < U; ++u) {
                 ok[u] = beg + t + u < end;
                 ii[u] = ok[u] ? P.col[beg + t + u] : 0;
-                if (P.row_active && ok[u] && !row_live(P, ii[u])) ok[u] = false, ii[u] = 0;
+                if (SP && P.row_active && ok[u] && !row_live(P, ii[u])) ok[u] = false, ii[u] = 0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -189,7 +193,7 @@ __device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk)
             for (int u = 0; u < U; ++u) {
                 ok[u] = beg + t + u < end;
                 int i = ok[u] ? P.col[beg + t + u] : 0;
-                if (P.row_active && ok[u] && !row_live(P, i)) ok[u] = false, i = 0;
+                if (SP && P.row_active && ok[u] && !row_live(P, i)) ok[u] = false, i = 0;
                 g[u] = ld4(row_at(P.feat + c4, i, P.ld_feat));
                 sd[u] = ld4(row_at(P.side + 4 * k, i, P.ld_side));
             }
@@ -216,7 +220,7 @@ __device__ __forceinline__ void bwd_short_rows(const AggGroup &P, const int blk)
 }
 
 // ------------------------------------------------------------------------------------------------ long rows / hub chunks
-template <int G, int MODE, int F4T>
+template <int G, int MODE, int F4T, bool SP>
 __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) {
     constexpr int NSG = kWave / G, U = 4;
     const int lane = (int)threadIdx.x % kWave;
@@ -231,7 +235,7 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
     const int F4 = P.F / 4, pos = sl % F4;
     const bool pow2 = (F4 & (F4 - 1)) == 0;
     const int k = c4 / P.F, nk = P.W / P.F;
-    const bool row_on = !P.row_active || P.row_active[row] != 0;  // see bwd_short_kernel
+    const bool row_on = !SP || !P.row_active || P.row_active[row] != 0;  // see bwd_short_kernel
     if (MODE == AGG_GAT_BWD_D && !row_on) {
         if (it.slot < 0 && sub == 0 && active && c4 % P.F == 0) P.ksum[(size_t)row * P.ld_k + k] = 0.f;
         return;  // hub chunks of such a row leave their partial records alone: the merge kernel does not read them
@@ -244,19 +248,19 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
     int src = it.beg + lane < it.end ? P.col[it.beg + lane] : -1;
-    if (kSrc && P.row_active && src >= 0 && !row_live(P, src)) src = -1;
+    if (SP && kSrc && P.row_active && src >= 0 && !row_live(P, src)) src = -1;
     // Batch-sparse S pass (the last layer: 2.5 % of the gathered rows carry a gradient): the surviving edges of SEVERAL batches
     // of 64 are queued (edge order kept) and processed together.  Packing each batch on its own (round 2) still paid one
     // whole 4-edges-per-subgroup iteration for the 1-2 survivors of nearly every batch: 0.32 ms to find and process the
     // 0.6 M live edges among 24.8 M.
     __shared__ int live_q[kBlock / kWave][kWave];
     const int wq = (int)threadIdx.x / kWave;
-    const bool queued = kSrc && P.row_active != nullptr;
+    const bool queued = SP && kSrc && P.row_active != nullptr;
     int q_n = 0;
     for (int base = it.beg; base < it.end; base += kWave) {
         const int nxt = base + kWave + lane;
         int src_next = nxt < it.end ? P.col[nxt] : -1;
-        if (kSrc && P.row_active && src_next >= 0 && !row_live(P, src_next)) src_next = -1;
+        if (SP && kSrc && P.row_active && src_next >= 0 && !row_live(P, src_next)) src_next = -1;
         int cnt = min(kWave, it.end - base);
         if (queued) {
             const unsigned long long live = __ballot(src >= 0);
@@ -365,17 +369,17 @@ __device__ __forceinline__ void bwd_long_item(const AggGroup &P, const int blk) 
 
 // One launch per pass and lane width, like the forward's agg_rows_kernel: workgroups [0, n_long_blocks) take the long rows
 // and hub chunks, the rest the short rows (they fill the machine while the last long items drain).
-template <int G, int MODE, int F4T>
+template <int G, int MODE, int F4T, bool SP>
 __global__ __launch_bounds__(kBlock) void bwd_rows_kernel(const AggLaunch L) {
     if ((int)blockIdx.x >= L.n_long_blocks) {
         const int b = (int)blockIdx.x - L.n_long_blocks;
         int gi = 0;
         while (gi + 1 < L.n_groups && b >= L.blk_short[gi + 1]) ++gi;
-        bwd_short_rows<G, MODE, F4T>(L.g[gi], b - L.blk_short[gi]);
+        bwd_short_rows<G, MODE, F4T, SP>(L.g[gi], b - L.blk_short[gi]);
         return;
     }
     const int gi = find_group(L);
-    bwd_long_item<G, MODE, F4T>(L.g[gi], (int)blockIdx.x - L.blk_start[gi]);
+    bwd_long_item<G, MODE, F4T, SP>(L.g[gi], (int)blockIdx.x - L.blk_start[gi]);
 }
 
 // ------------------------------------------------------------------------------------------------ hub rows
@@ -487,7 +491,8 @@ int launch_bwd_g(const AggLaunch &base, const int *sel, int n_sel, hipStream_t s
         L.n_long_blocks = blocks;
         if (blocks + sblocks > 0) {
             ProfScope ps(nm, stream, pulled, pulled, table);
-            PEA_LAUNCH((bwd_rows_kernel<G, MODE, F4T>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
+            if (sparse) PEA_LAUNCH((bwd_rows_kernel<G, MODE, F4T, true>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
+            else PEA_LAUNCH((bwd_rows_kernel<G, MODE, F4T, false>), dim3(blocks + sblocks), dim3(kBlock), 0, stream, L);
             PEA_HIP(hipGetLastError());
         }
     }
